@@ -1,0 +1,121 @@
+/* libq3asr -- C ABI of the MI355X (gfx950) Qwen3-ASR offline-transcription hot path.
+ *
+ * The reference (seichris/qwen3-asr-swift) has no FFI seam for this path: its Swift modules call
+ * MLX directly.  This header is the seam a Swift host would bind: the host
+ * keeps Qwen3ASRModel.fromPretrained / transcribe(audio:sampleRate:) and its safetensors loader and
+ * calls these entry points.  Every declaration cites the reference code it replaces, as
+ * Sources/Qwen3ASR/<file>:<lines>.
+ *
+ * Conventions: plain C; every function returns 0 on success and a non-zero code on failure, with a
+ * thread-local message available from q3asr_last_error().  The caller owns all buffers it passes;
+ * the library owns all device memory it allocates.  A model is immutable after q3asr_finalize and
+ * may be driven from one host thread at a time (calls are synchronous, like transcribe).
+ * "space" arguments say where a caller buffer lives: Q3ASR_HOST or Q3ASR_DEVICE (HIP device memory
+ * of the model's GPU).
+ */
+#ifndef Q3ASR_H
+#define Q3ASR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct q3asr_model q3asr_model;
+
+enum { Q3ASR_HOST = 0, Q3ASR_DEVICE = 1 };
+enum { Q3ASR_F32 = 0, Q3ASR_BF16 = 1, Q3ASR_U32 = 2 };
+
+/* Model hyper-parameters: Qwen3AudioEncoderConfig (AudioEncoder.swift:7-43) and TextDecoderConfig
+ * (Configuration.swift:46-110) plus the switches that change numerics. */
+typedef struct q3asr_config {
+    int enc_d_model, enc_heads, enc_ffn, enc_layers, n_mels, enc_out_dim, conv_channels, n_window, n_window_infer;
+    float ln_eps;
+    int vocab, hidden, layers, heads, kv_heads, head_dim, inter;
+    float rms_eps, rope_theta;
+    int rope_interleaved, rotary_dim; /* Configuration.swift:62,75-80 */
+    int group_size, bits;             /* Configuration.swift:67-68 */
+    int weight_format;                /* 0: dense bf16 decoder (TextDecoder.swift), 1: MLX affine q4 (QuantizedTextDecoder.swift) */
+    int embed_scale;                  /* Qwen3ASR.swift:190-196, default 1 */
+    int max_batch;                    /* utterances decoded together on this GPU */
+} q3asr_config;
+
+/* Last error message of the calling thread ("" if none). */
+const char* q3asr_last_error(void);
+
+/* Qwen3ASRModel.init (Qwen3ASR.swift:33-42): allocate a model for `cfg` on HIP device `device`. */
+int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out);
+void q3asr_destroy(q3asr_model* m);
+
+/* WeightLoader (WeightLoading.swift:92-127, 151-176, 183-347): hand over one checkpoint tensor by
+ * its safetensors key ("audio_tower.conv2d1.weight", "model.layers.0.self_attn.q_proj.scales", ...).
+ * `data` is a host pointer borrowed for the duration of the call.  Conv weights arrive in the
+ * checkpoint's [out, kH, kW, in] layout (WeightLoading.swift:277-284). */
+int q3asr_load_tensor(q3asr_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* data);
+/* Ends loading: re-lays weights out for the kernels and moves them to HBM.  Unlike the reference,
+ * which silently skips absent keys (WeightLoading.swift:190-203), a missing or mis-shaped tensor is an error. */
+int q3asr_finalize(q3asr_model* m);
+
+/* WhisperFeatureExtractor.setupMelFilterbank (AudioPreprocessing.swift:23-126): the [128][201] fp32 filterbank. */
+int q3asr_mel_filterbank(q3asr_model* m, float* out);
+
+/* WhisperFeatureExtractor.process (AudioPreprocessing.swift:330-344; resample :347-365, extractFeatures
+ * :131-324), batched.  audio: concatenated mono samples, utterance u = audio[offsets[u] .. offsets[u+1]).
+ * mel_out: [n_utt][128][t_stride] fp32, row u/m holds n_frames[u] values (t_stride >= 3000 is always enough). */
+int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_utt, int sample_rate, int audio_space,
+              float* mel_out, int t_stride, int32_t* n_frames, int out_space);
+
+/* Qwen3AudioEncoder.callAsFunction (AudioEncoder.swift:325-501), batched.  mel: [n_utt][128][t_stride]
+ * as produced by q3asr_mel.  embeds_out: packed [sum N_u][enc_out_dim] fp32; cu_tokens[n_utt+1] (host)
+ * receives the row offsets.  getOutputLength (AudioEncoder.swift:254-270) is q3asr_output_length. */
+int q3asr_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t* n_frames, int n_utt, int mel_space,
+                 float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space);
+int q3asr_output_length(const q3asr_model* m, int n_frames);
+
+typedef struct q3asr_request {
+    const float* audio;          /* concatenated samples */
+    const int64_t* offsets;      /* [n_utt + 1] (host) */
+    int n_utt;
+    int sample_rate;
+    int audio_space;
+    const int32_t* lang_ids;     /* tokenised " language X<asr_text>" prefixes, concatenated (host) or NULL: Qwen3ASR.swift:302-309 */
+    const int32_t* lang_offsets; /* [n_utt + 1] or NULL */
+    int max_tokens;              /* Qwen3ASR.swift:64, default 448 */
+    int stop_rules;              /* 1: EOS / control-token / repetition stops of Qwen3ASR.swift:571-627; 0: run max_tokens steps */
+    const int32_t* forced_tokens;/* [n_utt][max_tokens] teacher-forced decoder inputs (parity tests) or NULL */
+    /* debug taps (host pointers, may be NULL) */
+    float* tap_logits;           /* [n_utt][tap_steps][vocab] fp32 logits of the first tap_steps steps */
+    int tap_steps;
+    float* tap_audio_embeds;     /* packed [sum N_u][enc_out_dim] in request order */
+    float* tap_inputs_embeds;    /* packed [sum S_u][hidden] spliced prompt embeddings in request order */
+} q3asr_request;
+
+typedef struct q3asr_result {
+    int32_t* tokens;             /* [n_utt][max_tokens] (host, caller-allocated) */
+    int32_t* n_tokens;           /* [n_utt] */
+    int32_t* n_audio_tokens;     /* [n_utt] or NULL */
+    double audio_seconds;        /* sum over utterances of the 16 kHz duration actually transcribed (<= 30 s each) */
+    double ms_mel, ms_encoder, ms_prefill, ms_decode; /* device time per stage (HIP events) */
+    int64_t decode_steps;        /* batched decode steps executed */
+    int64_t tokens_total;
+} q3asr_result;
+
+/* Qwen3ASRModel.transcribe up to the token list (Qwen3ASR.swift:60-145; _generateText :170-632):
+ * mel -> encoder -> prompt ids / embedding / std rescale / splice (:229-363) -> prefill (:380-389) ->
+ * greedy KV-cache loop with the stop rules (:562-632), for a batch of utterances. */
+int q3asr_transcribe_tokens(q3asr_model* m, const q3asr_request* req, q3asr_result* res);
+
+/* Kernel-level entry points used by the parity tests (host buffers).
+ * q3asr_op_gemm: out[M][N] fp32 = act(A[M][K] * W[N][K]^T + bias), bf16 operands; tile / ksplit select the kernel variant. */
+int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const float* bias, int M, int N, int K, int gelu,
+                  int tile, int ksplit, float* out);
+/* q3asr_op_gemm_q4: the dequant-fused variant, MLX affine 4-bit weights (QuantizedTextDecoder.swift:54-67). */
+int q3asr_op_gemm_q4(q3asr_model* m, const uint16_t* a, const uint32_t* wq, const uint16_t* scales, const uint16_t* biases,
+                     int M, int N, int K, int tile, float* out);
+/* q3asr_op_attention: packed varlen attention; q/k/v [rows][heads*head_dim] bf16 (kv heads = heads / group). */
+int q3asr_op_attention(q3asr_model* m, const uint16_t* q, const uint16_t* k, const uint16_t* v, const int32_t* cu_seqlens,
+                       int n_seq, int heads, int group, int head_dim, int causal, uint16_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

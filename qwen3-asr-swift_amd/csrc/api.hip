@@ -1,0 +1,228 @@
+// extern "C" surface of libq3asr (declared in include/q3asr.h).
+#include "model.h"
+#include <cstring>
+
+static thread_local std::string g_last_error;
+void q3_set_error(const std::string& msg) { g_last_error = msg; }
+
+#define Q3_API_BEGIN try {
+#define Q3_API_END                         \
+    g_last_error.clear();                  \
+    return 0;                              \
+    }                                      \
+    catch (const std::exception& e) {      \
+        g_last_error = e.what();           \
+        return 1;                          \
+    }                                      \
+    catch (...) {                          \
+        g_last_error = "q3asr: unknown error"; \
+        return 2;                          \
+    }
+
+extern "C" {
+
+const char* q3asr_last_error(void) { return g_last_error.c_str(); }
+
+int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(cfg && out, "create: null argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) throw Q3Error("q3asr: no HIP device available (this library has no CPU path)");
+    Q3_REQUIRE(device >= 0 && device < ndev, "create: device ordinal out of range");
+    Q3_REQUIRE(cfg->n_mels == 128 && cfg->n_window == 50, "create: kernels are built for 128 mel bins and 100-frame chunks");
+    Q3_REQUIRE(cfg->head_dim == 128, "create: decoder head_dim must be 128");
+    Q3_REQUIRE(cfg->enc_d_model % cfg->enc_heads == 0 && cfg->enc_d_model / cfg->enc_heads == 64, "create: encoder head_dim must be 64");
+    Q3_REQUIRE(cfg->heads % cfg->kv_heads == 0, "create: heads must be a multiple of kv_heads");
+    Q3_REQUIRE(cfg->enc_d_model % 32 == 0 && cfg->enc_ffn % 32 == 0 && cfg->hidden % 64 == 0 && cfg->inter % 64 == 0 &&
+                   cfg->conv_channels % 32 == 0 && cfg->enc_out_dim % 4 == 0,
+               "create: layer widths must be multiples of 32 (64 for the decoder)");
+    Q3_REQUIRE(cfg->enc_d_model <= 2048 && cfg->hidden <= 2048, "create: model width above 2048 is not supported by the norm kernels");
+    Q3_REQUIRE(cfg->rotary_dim > 0 && cfg->rotary_dim % 4 == 0 && cfg->rotary_dim <= cfg->head_dim, "create: rotary_dim must be a multiple of 4 within head_dim");
+    Q3_REQUIRE(cfg->weight_format == 0 || cfg->weight_format == 1, "create: unknown weight_format");
+    HIP_CHECK(hipSetDevice(device));
+    q3asr_model* m = new q3asr_model();
+    m->cfg = *cfg;
+    m->device = device;
+    try {
+        HIP_CHECK(hipStreamCreate(&m->stream));
+        m->zero_page = m->dalloc<bf16_t>(512);
+        HIP_CHECK(hipMemset(m->zero_page, 0, 1024));
+        mel_tables_create(m->mel);
+    } catch (...) {
+        q3asr_destroy(m);
+        throw;
+    }
+    *out = m;
+    Q3_API_END
+}
+
+void q3asr_destroy(q3asr_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    mel_tables_destroy(m->mel);
+    m->arena.release();
+    for (void* p : m->owned) (void)hipFree(p);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int q3asr_load_tensor(q3asr_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* data) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && name && shape && data, "load_tensor: null argument");
+    Q3_REQUIRE(!m->finalized, "load_tensor: model already finalized");
+    Q3_REQUIRE(ndim >= 1 && ndim <= 4, "load_tensor: rank must be 1..4");
+    Q3_REQUIRE(dtype == Q3ASR_F32 || dtype == Q3ASR_BF16 || dtype == Q3ASR_U32, "load_tensor: unknown dtype");
+    HostTensor t;
+    t.dtype = dtype;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        Q3_REQUIRE(shape[i] > 0, "load_tensor: non-positive dimension");
+        t.shape.push_back(shape[i]);
+        n *= shape[i];
+    }
+    const size_t bytes = (size_t)n * (dtype == Q3ASR_BF16 ? 2 : 4);
+    t.data.assign((const uint8_t*)data, (const uint8_t*)data + bytes);
+    m->host[name] = std::move(t);
+    Q3_API_END
+}
+
+int q3asr_finalize(q3asr_model* m) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m, "finalize: null model");
+    model_finalize(m);
+    Q3_API_END
+}
+
+int q3asr_mel_filterbank(q3asr_model* m, float* out) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && out, "mel_filterbank: null argument");
+    memcpy(out, m->mel.host_fb.data(), m->mel.host_fb.size() * 4);
+    Q3_API_END
+}
+
+int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_utt, int sample_rate, int audio_space,
+              float* mel_out, int t_stride, int32_t* n_frames, int out_space) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m, "mel: null model");
+    model_mel(m, audio, offsets, n_utt, sample_rate, audio_space, mel_out, t_stride, n_frames, out_space);
+    Q3_API_END
+}
+
+int q3asr_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t* n_frames, int n_utt, int mel_space,
+                 float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m, "encode: null model");
+    model_encode(m, mel, t_stride, n_frames, n_utt, mel_space, embeds_out, out_rows_capacity, cu_tokens, out_space);
+    Q3_API_END
+}
+
+int q3asr_output_length(const q3asr_model* m, int n_frames) { return m ? model_output_length(m->cfg, n_frames) : -1; }
+
+int q3asr_transcribe_tokens(q3asr_model* m, const q3asr_request* req, q3asr_result* res) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m, "transcribe: null model");
+    model_transcribe(m, req, res);
+    Q3_API_END
+}
+
+// ---- kernel-level entry points for the parity tests ----
+int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const float* bias, int M, int N, int K, int gelu,
+                  int tile, int ksplit, float* out) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && a && w && out, "op_gemm: null argument");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    bf16_t* da = m->arena.get<bf16_t>((size_t)M * K);
+    bf16_t* dw = m->arena.get<bf16_t>((size_t)N * K);
+    float* db = bias ? m->arena.get<float>(N) : nullptr;
+    float* dout = m->arena.get<float>((size_t)M * N * std::max(1, ksplit));
+    HIP_CHECK(hipMemcpyAsync(da, a, (size_t)M * K * 2, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(dw, w, (size_t)N * K * 2, hipMemcpyHostToDevice, m->stream));
+    if (bias) HIP_CHECK(hipMemcpyAsync(db, bias, (size_t)N * 4, hipMemcpyHostToDevice, m->stream));
+    GemmParams p;
+    p.A = da; p.lda = K; p.W = dw; p.M = M; p.N = N; p.K = K; p.zero = m->zero_page;
+    p.out = dout; p.ldo = N;
+    if (ksplit > 1) {
+        Q3_REQUIRE(!bias && !gelu, "op_gemm: split-K has no bias / activation");
+        p.ksplit = ksplit; p.slab_stride = (int64_t)M * N;
+        launch_gemm(p, A_PLAIN, OUT_SLAB, W_BF16, tile, m->stream);
+        std::vector<float> h((size_t)M * N * ksplit);
+        HIP_CHECK(hipMemcpyAsync(h.data(), dout, h.size() * 4, hipMemcpyDeviceToHost, m->stream));
+        HIP_CHECK(hipStreamSynchronize(m->stream));
+        for (size_t i = 0; i < (size_t)M * N; ++i) {
+            float s = 0.f;
+            for (int z = 0; z < ksplit; ++z) s += h[(size_t)z * M * N + i];
+            out[i] = s;
+        }
+    } else {
+        p.bias = db; p.act = gelu ? 1 : 0;
+        launch_gemm(p, A_PLAIN, OUT_F32, W_BF16, tile, m->stream);
+        HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost, m->stream));
+        HIP_CHECK(hipStreamSynchronize(m->stream));
+    }
+    Q3_API_END
+}
+
+int q3asr_op_gemm_q4(q3asr_model* m, const uint16_t* a, const uint32_t* wq, const uint16_t* scales, const uint16_t* biases,
+                     int M, int N, int K, int tile, float* out) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && a && wq && scales && biases && out, "op_gemm_q4: null argument");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    bf16_t* da = m->arena.get<bf16_t>((size_t)M * K);
+    uint32_t* dw = m->arena.get<uint32_t>((size_t)N * K / 8);
+    bf16_t* ds = m->arena.get<bf16_t>((size_t)N * K / 64);
+    bf16_t* db = m->arena.get<bf16_t>((size_t)N * K / 64);
+    float* dout = m->arena.get<float>((size_t)M * N);
+    HIP_CHECK(hipMemcpyAsync(da, a, (size_t)M * K * 2, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(dw, wq, (size_t)N * K / 8 * 4, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(ds, scales, (size_t)N * K / 64 * 2, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(db, biases, (size_t)N * K / 64 * 2, hipMemcpyHostToDevice, m->stream));
+    GemmParams p;
+    p.A = da; p.lda = K; p.W = dw; p.qscales = ds; p.qbiases = db; p.qgroup = 64;
+    p.M = M; p.N = N; p.K = K; p.zero = m->zero_page; p.out = dout; p.ldo = N;
+    launch_gemm(p, A_PLAIN, OUT_F32, W_Q4, tile, m->stream);
+    HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    Q3_API_END
+}
+
+int q3asr_op_attention(q3asr_model* m, const uint16_t* q, const uint16_t* k, const uint16_t* v, const int32_t* cu_seqlens,
+                       int n_seq, int heads, int group, int head_dim, int causal, uint16_t* out) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && q && k && v && cu_seqlens && out && n_seq > 0, "op_attention: null argument");
+    Q3_REQUIRE(group > 0 && heads % group == 0, "op_attention: heads must be a multiple of group");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    const int rows = cu_seqlens[n_seq], kvh = heads / group;
+    const size_t qn = (size_t)rows * heads * head_dim, kn = (size_t)rows * kvh * head_dim;
+    bf16_t* dq = m->arena.get<bf16_t>(qn);
+    bf16_t* dk = m->arena.get<bf16_t>(kn);
+    bf16_t* dv = m->arena.get<bf16_t>(kn);
+    bf16_t* dout = m->arena.get<bf16_t>(qn);
+    HIP_CHECK(hipMemcpyAsync(dq, q, qn * 2, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(dk, k, kn * 2, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(dv, v, kn * 2, hipMemcpyHostToDevice, m->stream));
+    std::vector<AttnSeq> seqs;
+    std::vector<AttnTile> tiles;
+    for (int s = 0; s < n_seq; ++s) {
+        const int r0 = cu_seqlens[s], len = cu_seqlens[s + 1] - r0;
+        Q3_REQUIRE(len > 0, "op_attention: empty sequence");
+        seqs.push_back({r0, len, (int64_t)r0 * kvh * head_dim});
+        for (int q0 = 0; q0 < len; q0 += 64) tiles.push_back({s, q0});
+    }
+    AttnSeq* dseq = m->arena.get<AttnSeq>(seqs.size());
+    AttnTile* dtile = m->arena.get<AttnTile>(tiles.size());
+    HIP_CHECK(hipMemcpyAsync(dseq, seqs.data(), seqs.size() * sizeof(AttnSeq), hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemcpyAsync(dtile, tiles.data(), tiles.size() * sizeof(AttnTile), hipMemcpyHostToDevice, m->stream));
+    FlashParams fp{dq, (int64_t)heads * head_dim, dk, dv, (int64_t)kvh * head_dim, head_dim, dout, (int64_t)heads * head_dim,
+                   dseq, dtile, (int)tiles.size(), heads, group, 1.0f / sqrtf((float)head_dim), causal};
+    launch_flash_attn(fp, head_dim, m->stream);
+    HIP_CHECK(hipMemcpyAsync(out, dout, qn * 2, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    Q3_API_END
+}
+
+}  // extern "C"

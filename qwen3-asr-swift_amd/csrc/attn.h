@@ -1,0 +1,37 @@
+// Attention kernels (gfx950): MFMA flash attention over packed variable-length sequences
+// (encoder windows, decoder prefill) and the single-query KV-cache decode step.
+#pragma once
+#include "common.h"
+
+struct AttnSeq {       // one attention problem (an encoder window, or one utterance's prompt)
+    int q_row0;        // first row of the sequence in the packed Q / O buffers
+    int len;           // number of queries == number of keys
+    int64_t kv_off;    // element offset of (key 0, kv-head 0) from the K / V base pointers
+};
+struct AttnTile {      // one workgroup: 64 consecutive queries of one sequence
+    int seq;
+    int q0;
+};
+
+struct FlashParams {
+    const bf16_t* Q; int64_t q_ld;          // Q[row][head*D + d]
+    const bf16_t* K; const bf16_t* V;       // K/V[kv_off + key*kv_ld + kvhead*kv_hs + d]
+    int64_t kv_ld, kv_hs;
+    bf16_t* O; int64_t o_ld;                // O[row][head*D + d]
+    const AttnSeq* seqs; const AttnTile* tiles; int n_tiles;
+    int heads, group;                       // group = q heads per kv head
+    float scale;
+    int causal;
+};
+void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s);
+
+struct DecodeAttnParams {
+    const bf16_t* Q; int64_t q_ld;          // Q[u][head*D + d] (already normalised + rotated)
+    const bf16_t* K; const bf16_t* V;       // cache[u*utt_stride + kvhead*head_stride + pos*D + d]
+    int64_t utt_stride, head_stride;
+    const int* lens; int len_add;           // keys visible to utterance u = lens[u] + len_add
+    bf16_t* O; int64_t o_ld;
+    int B, kv_heads, group;
+    float scale;
+};
+void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s);

@@ -1,0 +1,291 @@
+// Attention kernels for gfx950.
+//
+// flash_kernel: softmax(Q K^T * scale [+ causal mask]) V over packed variable-length sequences
+// (reference: dense masked attention at AudioEncoder.swift:83-91 with the block mask of :303-320,
+// and QuantizedTextDecoder.swift:188-201 with the causal mask of :364-381 and GQA tiling :171-185;
+// the additive -1e9 masks are realised by skipping the masked keys, which is what they evaluate
+// to in fp32).  One workgroup = 64 queries x one head, 4 waves x 16 queries; K/V tiles of 32 keys
+// are register-staged into LDS (K row-major, V transposed).  The scores are computed transposed
+// (S^T = K Q^T) so each lane owns one query column: the row statistics need two shuffles, and the
+// exponentiated accumulator is directly the B operand of O^T = V^T P^T (no LDS round trip for P).
+//
+// decode_attn_kernel: one new query per utterance against its KV cache (GQA group shares the
+// K/V stream).  HBM-bound: K rows go straight from global memory into MFMA A fragments, the
+// probabilities are exchanged through a few LDS words, V rows are consumed coalesced by the VALU.
+#include "attn.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+union Frag {
+    bf16x8 v;
+    uint4 u;
+    uint2 h[2];
+};
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
+    constexpr int KS = D * 2 + 16;  // K row stride in LDS (bytes)
+    constexpr int VS = 80;          // V^T row stride: 32 keys * 2 B + 16
+    constexpr int KCH = D / 8;      // 16-byte chunks per row
+    constexpr int NLD = 32 * KCH / 256;
+    constexpr int NKS = D / 32, NDT = D / 16;
+    __shared__ __attribute__((aligned(16))) char lds[32 * KS + D * VS];
+    char* kl = lds;
+    char* vl = lds + 32 * KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const AttnTile tile = p.tiles[blockIdx.x];
+    const AttnSeq seq = p.seqs[tile.seq];
+    const int h = blockIdx.y, kvh = h / p.group;
+    const int len = seq.len, q0 = tile.q0;
+    const int qi = q0 + 16 * wave + li;
+    const int64_t qrow = seq.q_row0 + min(qi, len - 1);
+
+    Frag qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks].u = *(const uint4*)(p.Q + qrow * p.q_ld + h * D + 32 * ks + 8 * lg);
+
+    const int kv_end = CAUSAL ? min(len, q0 + 64) : len;
+    const int ntiles = (kv_end + 31) >> 5;
+    const bf16_t* Kb = p.K + seq.kv_off + (int64_t)kvh * p.kv_hs;
+    const bf16_t* Vb = p.V + seq.kv_off + (int64_t)kvh * p.kv_hs;
+
+    uint4 kreg0, kreg1, vreg0, vreg1;
+    const int v_kp = tid & 15, v_ch = tid >> 4;  // V item: key pair, chunk
+    const int k_key0 = tid / KCH, k_ch0 = tid % KCH, k_key1 = (tid + 256) / KCH, k_ch1 = (tid + 256) % KCH;
+#define FLASH_LOAD(t)                                                                                   \
+    {                                                                                                   \
+        const int kv0_ = (t) * 32;                                                                      \
+        kreg0 = *(const uint4*)(Kb + (int64_t)min(kv0_ + k_key0, len - 1) * p.kv_ld + k_ch0 * 8);       \
+        if constexpr (NLD > 1)                                                                          \
+            kreg1 = *(const uint4*)(Kb + (int64_t)min(kv0_ + k_key1, len - 1) * p.kv_ld + k_ch1 * 8);   \
+        if (v_ch < KCH) {                                                                               \
+            vreg0 = *(const uint4*)(Vb + (int64_t)min(kv0_ + 2 * v_kp, len - 1) * p.kv_ld + v_ch * 8);  \
+            vreg1 = *(const uint4*)(Vb + (int64_t)min(kv0_ + 2 * v_kp + 1, len - 1) * p.kv_ld + v_ch * 8); \
+        }                                                                                               \
+    }
+    FLASH_LOAD(0);
+
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        *(uint4*)(kl + k_key0 * KS + k_ch0 * 16) = kreg0;
+        if constexpr (NLD > 1) *(uint4*)(kl + k_key1 * KS + k_ch1 * 16) = kreg1;
+        if (v_ch < KCH) {
+            const uint32_t aw[4] = {vreg0.x, vreg0.y, vreg0.z, vreg0.w};
+            const uint32_t bw[4] = {vreg1.x, vreg1.y, vreg1.z, vreg1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t ae = (e & 1) ? (aw[e >> 1] >> 16) : (aw[e >> 1] & 0xffffu);
+                const uint32_t be = (e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16);
+                *(uint32_t*)(vl + (v_ch * 8 + e) * VS + v_kp * 4) = ae | be;
+            }
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) FLASH_LOAD(t + 1);
+        const int kv0 = t * 32;
+        if (CAUSAL && kv0 > q0 + 16 * wave + 15) continue;  // wave-uniform: every key is in the future
+
+        f32x4 s[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                Frag kf;
+                kf.u = *(const uint4*)(kl + (16 * nt + li) * KS + (lg + 4 * ks) * 16);
+                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qf[ks].v, s[nt], 0, 0, 0);
+            }
+        }
+        float sv[8], tmax = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kv0 + 16 * nt + 4 * lg + r;
+                const bool ok = key < len && (!CAUSAL || key <= qi);
+                sv[nt * 4 + r] = ok ? s[nt][r] * sl2 : -INFINITY;
+                tmax = fmaxf(tmax, sv[nt * 4 + r]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = exp2f(m - m_new);
+        float ps = 0.f, pe[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pe[j] = exp2f(sv[j] - m_new);
+            ps += pe[j];
+        }
+        Frag pf;
+        pf.u = make_uint4(pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3]), pack_bf16x2(pe[4], pe[5]),
+                          pack_bf16x2(pe[6], pe[7]));
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            o[dt] *= alpha;
+            Frag vf;
+            vf.h[0] = *(const uint2*)(vl + (16 * dt + li) * VS + 8 * lg);
+            vf.h[1] = *(const uint2*)(vl + (16 * dt + li) * VS + 32 + 8 * lg);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qi < len) {
+        const float inv = 1.0f / l;
+        bf16_t* orow = p.O + (seq.q_row0 + qi) * p.o_ld + h * D + 4 * lg;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            *(uint2*)(orow + 16 * dt) =
+                make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+    }
+}
+
+#undef FLASH_LOAD
+
+template <int GROUP>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
+    constexpr int D = 128;
+    __shared__ float pl[4][GROUP][16];
+    __shared__ float al[4][GROUP];
+    __shared__ float sm_m[4][GROUP], sm_l[4][GROUP];
+    __shared__ float so[4][GROUP][D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int u = blockIdx.x, kvh = blockIdx.y;
+    const int len = p.lens[u] + p.len_add;
+    const bf16_t* Kb = p.K + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
+    const bf16_t* Vb = p.V + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
+
+    Frag qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks].u = make_uint4(0, 0, 0, 0);
+        if (li < GROUP) qf[ks].u = *(const uint4*)(p.Q + (int64_t)u * p.q_ld + (kvh * GROUP + li) * D + 32 * ks + 8 * lg);
+    }
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    float m = -INFINITY, l = 0.f;
+    float o[GROUP][2];
+#pragma unroll
+    for (int q = 0; q < GROUP; ++q) o[q][0] = o[q][1] = 0.f;
+    volatile float* vpl = &pl[wave][0][0];
+    volatile float* val = &al[wave][0];
+
+    const int ntiles = (len + 15) >> 4;
+    for (int t = wave; t < ntiles; t += 4) {
+        const int kv0 = t * 16;
+        const int key = min(kv0 + li, len - 1);
+        Frag kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks].u = *(const uint4*)(Kb + (int64_t)key * D + 32 * ks + 8 * lg);
+        uint32_t vv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) vv[k] = *(const uint32_t*)(Vb + (int64_t)min(kv0 + k, len - 1) * D + 2 * lane);
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks].v, qf[ks].v, s, 0, 0, 0);
+        float sv[4], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sv[r] = (kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;
+            tmax = fmaxf(tmax, sv[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = exp2f(m - m_new);
+        float pr[4], ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pr[r] = exp2f(sv[r] - m_new);
+            ps += pr[r];
+        }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+        if (li < GROUP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vpl[li * 16 + 4 * lg + r] = pr[r];
+            if (lg == 0) val[li] = alpha;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q) {
+            const float a = val[q];
+            float ox = o[q][0] * a, oy = o[q][1] * a;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float pk = vpl[q * 16 + k];
+                ox = fmaf(pk, __uint_as_float(vv[k] << 16), ox);
+                oy = fmaf(pk, __uint_as_float(vv[k] & 0xffff0000u), oy);
+            }
+            o[q][0] = ox;
+            o[q][1] = oy;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (li < GROUP && lg == 0) {
+        sm_m[wave][li] = m;
+        sm_l[wave][li] = l;
+    }
+#pragma unroll
+    for (int q = 0; q < GROUP; ++q) {
+        so[wave][q][2 * lane] = o[q][0];
+        so[wave][q][2 * lane + 1] = o[q][1];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < GROUP * D; idx += 256) {
+        const int q = idx / D, d = idx % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, sm_m[w][q]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = exp2f(sm_m[w][q] - M);
+            L += sm_l[w][q] * f;
+            O += so[w][q][d] * f;
+        }
+        p.O[(int64_t)u * p.o_ld + (kvh * GROUP + q) * D + d] = f32_to_bf16(O / L);
+    }
+}
+
+}  // namespace
+
+void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s) {
+    if (p.n_tiles <= 0) return;
+    Q3_REQUIRE(head_dim == 64 || head_dim == 128, "flash attention: head_dim must be 64 or 128");
+    Q3_REQUIRE(p.q_ld % 8 == 0 && p.kv_ld % 8 == 0 && p.kv_hs % 8 == 0 && p.o_ld % 4 == 0, "flash attention: misaligned strides");
+    dim3 grid(p.n_tiles, p.heads), block(256);
+    if (head_dim == 64) {
+        if (p.causal) hipLaunchKernelGGL((flash_kernel<64, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_kernel<64, false>), grid, block, 0, s, p);
+    } else {
+        if (p.causal) hipLaunchKernelGGL((flash_kernel<128, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_kernel<128, false>), grid, block, 0, s, p);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s) {
+    if (p.B <= 0) return;
+    Q3_REQUIRE(head_dim == 128, "decode attention: head_dim must be 128");
+    dim3 grid(p.B, p.kv_heads), block(256);
+    switch (p.group) {
+        case 1: hipLaunchKernelGGL((decode_attn_kernel<1>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((decode_attn_kernel<2>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((decode_attn_kernel<4>), grid, block, 0, s, p); break;
+        default: throw Q3Error("decode attention: GQA group must be 1, 2 or 4");
+    }
+    HIP_CHECK(hipGetLastError());
+}

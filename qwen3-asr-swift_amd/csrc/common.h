@@ -1,0 +1,53 @@
+// Shared declarations for libq3asr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <stdexcept>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bit pattern
+
+struct Q3Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+void q3_set_error(const std::string& msg);
+
+#define HIP_CHECK(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            throw Q3Error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " +  \
+                          __FILE__ + ":" + std::to_string(__LINE__));                          \
+    } while (0)
+
+#define Q3_REQUIRE(cond, msg)                                   \
+    do {                                                        \
+        if (!(cond)) throw Q3Error(std::string("q3asr: ") + (msg)); \
+    } while (0)
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// Round-to-nearest-even; inputs here are finite activations / weights.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

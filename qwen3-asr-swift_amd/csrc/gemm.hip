@@ -1,0 +1,357 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * W[N,K]^T, fp32 accumulate, fused epilogues.
+//
+// Tile BM x BN x 64 per 256-thread workgroup (4 waves as 2 x 2), mfma_f32_16x16x32_bf16.
+// Both operands are K-contiguous in memory; tiles are staged global -> LDS by 16-byte
+// global_load_lds (LDS image lane-linear, XOR swizzle applied on the source chunk and on the
+// fragment read), double buffered, one barrier per K tile.
+//
+// The weight fragment is fed as the MFMA "A" operand and the activation fragment as "B", so an
+// accumulator register holds consecutive OUTPUT COLUMNS of one row.  Weight rows are assigned to
+// MFMA rows through a permutation that makes every lane own 4*NT contiguous columns of a row, so
+// the epilogue stores 16-byte vectors.
+#include "gemm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+namespace {
+
+struct ConvRow {
+    int64_t base;
+    int iy0, ix0, wv;
+};
+
+template <int MT, int NT, int AMODE, int OUT, int WFMT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int AP = BM * 8 / 256, WP = BN * 8 / 256;  // 16-byte chunks per thread per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    const int li = lane & 15, lg = lane >> 4;
+
+    // ---- workgroup -> tile: XCD-contiguous remap, then groups of 8 M-tiles share each N-tile ----
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int L;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int grp = L / per_group, first_m = grp * GROUP;
+    const int gsz = min(GROUP, tiles_m - first_m);
+    const int tm = first_m + (L % per_group) % gsz, tn = (L % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- K range of this split ----
+    const int nk_total = (p.K + 63) >> 6;
+    const int per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int kt0 = blockIdx.z * per, kt1 = min(nk_total, kt0 + per);
+
+    // ---- per-thread source descriptors ----
+    const bf16_t* a_src[AP];
+    ConvRow crow[AP];
+    int a_koff[AP];
+#pragma unroll
+    for (int q = 0; q < AP; ++q) {
+        const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
+        const int sc = cc ^ ((row >> 1) & 7);
+        a_koff[q] = sc * 8;
+        const int m = min(m0 + row, p.M - 1);
+        if constexpr (AMODE == A_PLAIN) {
+            a_src[q] = p.A + (int64_t)m * p.lda + sc * 8;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int chunk = m / hw, rem = m - chunk * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            crow[q].base = (int64_t)chunk * p.Hin * p.Win * p.Cin;
+            crow[q].iy0 = 2 * oy - 1;
+            crow[q].ix0 = 2 * ox - 1;
+            crow[q].wv = min(p.Win, p.win_valid ? p.win_valid[chunk] : p.Win);
+        }
+    }
+    const bf16_t* w_src[WP];
+    int w_koff[WP];
+    if constexpr (WFMT == W_BF16) {
+#pragma unroll
+        for (int q = 0; q < WP; ++q) {
+            const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
+            const int f = ((row >> 1) & 1) | (((row / (4 * NT)) & 3) << 1);
+            const int sc = cc ^ f;
+            w_koff[q] = sc * 8;
+            const int n = min(n0 + row, p.N - 1);
+            w_src[q] = (const bf16_t*)p.W + (int64_t)n * p.K + sc * 8;
+        }
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char* sa = smem + buf * STAGE;
+        char* sw = sa + A_BYTES;
+        const int kbase = kt * 64;
+#pragma unroll
+        for (int q = 0; q < AP; ++q) {
+            const bf16_t* src;
+            const int k0 = kbase + a_koff[q];
+            if constexpr (AMODE == A_PLAIN) {
+                src = (k0 < p.K) ? a_src[q] + kbase : p.zero;
+            } else {
+                const int khw = k0 / p.Cin, ci = k0 - khw * p.Cin;
+                const int kh = khw / 3, kw = khw - kh * 3;
+                const int iy = crow[q].iy0 + kh, ix = crow[q].ix0 + kw;
+                const bool ok = (k0 < p.K) && iy >= 0 && iy < p.Hin && ix >= 0 && ix < crow[q].wv;
+                src = ok ? p.A + crow[q].base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : p.zero;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sa + (q * 256 + uwave * 64) * 16), 16, 0, 0);
+        }
+        if constexpr (WFMT == W_BF16) {
+#pragma unroll
+            for (int q = 0; q < WP; ++q) {
+                const int k0 = kbase + w_koff[q];
+                const bf16_t* src = (k0 < p.K) ? w_src[q] + kbase : p.zero;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sw + (q * 256 + uwave * 64) * 16), 16, 0, 0);
+            }
+        } else {
+            // MLX affine 4-bit: one u32 = 8 codes = one 16-byte bf16 chunk; dequantised in registers
+            // (w = q * scale + bias, rounded to bf16) and written to the swizzled LDS slot.
+            const uint32_t* wq = (const uint32_t*)p.W;
+            const int groups = p.K / p.qgroup;
+#pragma unroll
+            for (int q = 0; q < WP; ++q) {
+                const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
+                const int f = ((row >> 1) & 1) | (((row / (4 * NT)) & 3) << 1);
+                const int sc = cc ^ f;
+                const int k0 = kbase + sc * 8;
+                const int n = min(n0 + row, p.N - 1);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (k0 < p.K) {
+                    const uint32_t code = wq[(int64_t)n * (p.K >> 3) + (k0 >> 3)];
+                    const float s = bf16_to_f32(p.qscales[(int64_t)n * groups + k0 / p.qgroup]);
+                    const float b = bf16_to_f32(p.qbiases[(int64_t)n * groups + k0 / p.qgroup]);
+                    float w[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = (float)((code >> (4 * j)) & 15u) * s + b;
+                    v = make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
+                                   pack_bf16x2(w[6], w[7]));
+                }
+                *(uint4*)(sw + c * 16) = v;
+            }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes within a stage)
+    int a_rd[2], w_rd[2];
+    {
+        const int fa = (li >> 1) & 7;
+        const int fw = ((li >> 1) & 1) | ((li >> 2) << 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a_rd[ks] = (wr * 16 * MT + li) * 128 + (((lg + 4 * ks) ^ fa) << 4);
+            w_rd[ks] = A_BYTES + (wc * 16 * NT + (li >> 2) * (4 * NT) + (li & 3)) * 128 + (((lg + 4 * ks) ^ fw) << 4);
+        }
+    }
+
+    if (kt0 < kt1) {
+        stage(0, kt0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+            const char* sb = smem + cur * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 wf[NT], af[MT];
+#pragma unroll
+                for (int b = 0; b < NT; ++b) wf[b] = *(const bf16x8*)(sb + w_rd[ks] + b * 4 * 128);
+#pragma unroll
+                for (int a = 0; a < MT; ++a) af[a] = *(const bf16x8*)(sb + a_rd[ks] + a * 16 * 128);
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], af[a], acc[a][b], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: lane (li, lg) owns row m, columns c0 .. c0 + 4*NT - 1 ----
+    const int c0 = n0 + wc * 16 * NT + lg * 4 * NT;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int m = m0 + wr * 16 * MT + a * 16 + li;
+        const bool row_ok = m < p.M;
+        int64_t orow = m;
+        if (row_ok && p.rowmap) orow = p.rowmap[m];
+        if constexpr (OUT == OUT_ARGMAX) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = c0 + b * 4 + r;
+                    const float v = acc[a][b][r];
+                    if (c < p.N && v > best) { best = v; bidx = c; }
+                }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bidx, o, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (row_ok && lg == 0) {
+                const int part = tn * 2 + wc;
+                p.part_val[(int64_t)m * p.nparts + part] = best;
+                p.part_idx[(int64_t)m * p.nparts + part] = bidx;
+            }
+            continue;
+        }
+        if (!row_ok || orow < 0) continue;
+        float v[4 * NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[b * 4 + r] = acc[a][b][r];
+        if constexpr (OUT == OUT_SLAB) {
+            float* o = (float*)p.out + blockIdx.z * p.slab_stride + orow * p.ldo + c0;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                if (c0 + b * 4 < p.N) *(float4*)(o + b * 4) = make_float4(v[b * 4], v[b * 4 + 1], v[b * 4 + 2], v[b * 4 + 3]);
+            continue;
+        }
+        if constexpr (OUT == OUT_SWIGLU) {
+            // weight rows come in blocks of 16: 8 gate rows then the 8 matching up rows
+            if (c0 < p.N) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = v[j], u = v[8 + j];
+                    y[j] = g / (1.0f + __expf(-g)) * u;
+                }
+                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + (c0 >> 1);
+                *(uint4*)o = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                                        pack_bf16x2(y[6], y[7]));
+            }
+            continue;
+        }
+        const float* rt = p.rowtab ? p.rowtab + (int64_t)(m % p.rowtab_period) * p.N : nullptr;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int c = c0 + b * 4;
+            if (c >= p.N) continue;
+            float x[4] = {v[b * 4], v[b * 4 + 1], v[b * 4 + 2], v[b * 4 + 3]};
+            if (p.bias) {
+                const float4 bb = *(const float4*)(p.bias + c);
+                x[0] += bb.x; x[1] += bb.y; x[2] += bb.z; x[3] += bb.w;
+            }
+            if (rt) {
+                const float4 tt = *(const float4*)(rt + c);
+                x[0] += tt.x; x[1] += tt.y; x[2] += tt.z; x[3] += tt.w;
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = gelu_erf(x[r]);
+            }
+            if constexpr (OUT == OUT_BF16) {
+                bf16_t* o = (bf16_t*)p.out + orow * p.ldo + c;
+                *(uint2*)o = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+            } else if constexpr (OUT == OUT_F32) {
+                float* o = (float*)p.out + orow * p.ldo + c;
+                *(float4*)o = make_float4(x[0], x[1], x[2], x[3]);
+            } else {  // OUT_F32_ACC
+                float* o = (float*)p.out + orow * p.ldo + c;
+                float4 old = *(float4*)o;
+                *(float4*)o = make_float4(old.x + x[0], old.y + x[1], old.z + x[2], old.w + x[3]);
+            }
+        }
+    }
+}
+
+template <int MT, int NT, int AMODE, int OUT, int WFMT>
+void launch_t(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t lds = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<MT, NT, AMODE, OUT, WFMT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<MT, NT, AMODE, OUT, WFMT>), dim3(tiles, 1, p.ksplit), dim3(256), lds, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int AMODE, int OUT, int WFMT>
+void launch_tile(const GemmParams& p, int tile, hipStream_t s) {
+    if (tile == 0) launch_t<4, 4, AMODE, OUT, WFMT>(p, s);
+    else if (tile == 1) {
+        if constexpr (OUT == OUT_SWIGLU) throw Q3Error("gemm: SwiGLU epilogue needs a 128-column tile");
+        else launch_t<2, 2, AMODE, OUT, WFMT>(p, s);
+    } else {
+        if constexpr (OUT == OUT_SWIGLU) launch_t<2, 4, AMODE, OUT, WFMT>(p, s);
+        else launch_t<4, 2, AMODE, OUT, WFMT>(p, s);
+    }
+}
+
+template <int AMODE, int WFMT>
+void launch_out(const GemmParams& p, GemmOut out, int tile, hipStream_t s) {
+    switch (out) {
+        case OUT_BF16: launch_tile<AMODE, OUT_BF16, WFMT>(p, tile, s); break;
+        case OUT_F32: launch_tile<AMODE, OUT_F32, WFMT>(p, tile, s); break;
+        case OUT_F32_ACC: launch_tile<AMODE, OUT_F32_ACC, WFMT>(p, tile, s); break;
+        case OUT_SWIGLU: launch_tile<AMODE, OUT_SWIGLU, WFMT>(p, tile, s); break;
+        case OUT_ARGMAX: launch_tile<AMODE, OUT_ARGMAX, WFMT>(p, tile, s); break;
+        case OUT_SLAB: launch_tile<AMODE, OUT_SLAB, WFMT>(p, tile, s); break;
+    }
+}
+
+}  // namespace
+
+int gemm_pick_tile(int M, int N) {
+    const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+    if (t128 >= 384) return 0;
+    return 1;
+}
+
+int gemm_argmax_parts(int N, int tile) {
+    const int bn = (tile == 0) ? 128 : 64;
+    return cdiv(N, bn) * 2;
+}
+
+void launch_gemm(const GemmParams& p, GemmAMode amode, GemmOut out, GemmWFmt wfmt, int tile, hipStream_t s) {
+    Q3_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
+    Q3_REQUIRE(p.K % 32 == 0 && p.N % 4 == 0, "gemm: K must be a multiple of 32 and N of 4");
+    Q3_REQUIRE(p.zero != nullptr, "gemm: zero page missing");
+    if (amode == A_PLAIN) Q3_REQUIRE(p.lda % 8 == 0 && p.lda >= p.K, "gemm: lda must be >= K and a multiple of 8");
+    else Q3_REQUIRE(p.K == 9 * p.Cin && p.Cin % 8 == 0, "gemm: conv K must be 9*Cin, Cin multiple of 8");
+    if (wfmt == W_Q4) Q3_REQUIRE(p.qgroup == 64 && p.K % 64 == 0, "gemm: q4 needs group 64 and K multiple of 64");
+    if (out == OUT_SWIGLU) Q3_REQUIRE(p.N % 16 == 0, "gemm: SwiGLU needs N multiple of 16");
+    if (out != OUT_SLAB) Q3_REQUIRE(p.ksplit == 1, "gemm: split-K only with slab output");
+    if (tile < 0) tile = gemm_pick_tile(p.M, p.N);
+    if (out == OUT_SWIGLU && tile == 1) tile = 2;
+    if (out == OUT_ARGMAX) Q3_REQUIRE(p.nparts == gemm_argmax_parts(p.N, tile == 2 ? 1 : tile), "gemm: nparts mismatch");
+    if (amode == A_PLAIN) {
+        if (wfmt == W_BF16) launch_out<A_PLAIN, W_BF16>(p, out, tile, s);
+        else launch_out<A_PLAIN, W_Q4>(p, out, tile, s);
+    } else {
+        Q3_REQUIRE(wfmt == W_BF16 && out == OUT_BF16, "gemm: conv path is bf16 weights / bf16 output");
+        launch_tile<A_CONV3X3S2, OUT_BF16, W_BF16>(p, tile, s);
+    }
+}

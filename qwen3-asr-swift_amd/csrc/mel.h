@@ -1,0 +1,38 @@
+// Log-mel frontend (resample -> STFT power -> slaney mel -> log10 -> max-8 clamp -> (x+4)/4).
+#pragma once
+#include "common.h"
+#include <vector>
+
+constexpr int MEL_NFFT = 400, MEL_HOP = 160, MEL_NMELS = 128, MEL_NBINS = 201, MEL_MAX_FRAMES = 3000;
+constexpr int MEL_TILE_FRAMES = 64;
+
+struct MelTables {           // device-resident constants, built once per model
+    float* hann = nullptr;   // [208]  periodic Hann, zero beyond n = 200
+    float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT
+    int* fb_lo = nullptr;    // [128] first FFT bin of each mel filter
+    int* fb_cnt = nullptr;   // [128] number of bins
+    int* fb_off = nullptr;   // [128] offset into fb_w
+    float* fb_w = nullptr;   // packed non-zero filter weights
+    std::vector<float> host_fb;  // dense [128][201] filterbank (host copy, for inspection / tests)
+};
+
+void mel_tables_create(MelTables& t);
+void mel_tables_destroy(MelTables& t);
+
+// Frames the reference produces before trimming: n/160 + 1; returned frames: min(n/160, 3000).
+static inline int mel_frames_total(int64_t n) { return (int)(n / MEL_HOP) + 1; }
+static inline int mel_frames_out(int64_t n) {
+    int t = mel_frames_total(n) - 1;
+    return t > MEL_MAX_FRAMES ? MEL_MAX_FRAMES : (t < 0 ? 0 : t);
+}
+
+// Linear-interpolation resample of one utterance (device pointers).
+void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, double ratio, hipStream_t s);
+
+// audio: concatenated 16 kHz samples; d_off[u] / d_len[u]: start and length of utterance u.
+// d_tile_utt / d_tile_f0: one entry per 64-frame tile.  out: [B][128][t_stride] raw log10 mel.
+// d_max: [B] order-preserving encodings of the per-utterance maximum (zeroed by the caller).
+void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
+                const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s);
+// In-place clamp / scale of rows [0, frames_out[u]) with the per-utterance maximum.
+void launch_mel_normalize(float* out, int B, int t_stride, const int* d_frames_out, const unsigned* d_max, hipStream_t s);

@@ -1,0 +1,130 @@
+// Host runtime of libq3asr: weights, workspace, and the batched transcription pipeline.
+#pragma once
+#include "../../include/q3asr.h"
+#include "common.h"
+#include "gemm.h"
+#include "attn.h"
+#include "ops.h"
+#include "mel.h"
+#include <map>
+#include <string>
+#include <vector>
+
+struct HostTensor {
+    std::vector<uint8_t> data;
+    std::vector<int64_t> shape;
+    int dtype = 0;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct LinearW {  // device-resident weight of one (possibly fused) linear, rows = output features
+    const void* w = nullptr;
+    const bf16_t* scales = nullptr;
+    const bf16_t* biases = nullptr;
+    int fmt = W_BF16;
+    int N = 0, K = 0;
+};
+
+struct EncLayerW {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    LinearW qkv, out, fc1, fc2;
+    float *qkv_b, *out_b, *fc1_b, *fc2_b;
+};
+
+struct DecLayerW {
+    float *in_norm, *post_norm, *q_norm, *k_norm;
+    LinearW qkv, o, gate_up, down;
+};
+
+// Bump allocator over a growing list of device blocks.  Blocks persist across calls, so a steady
+// stream of equally shaped batches allocates nothing after the first one.
+struct BlockArena {
+    struct Block {
+        char* p;
+        size_t cap, off;
+    };
+    std::vector<Block> blocks;
+    size_t cur = 0;
+    struct Mark {
+        size_t cur;
+        std::vector<size_t> offs;
+    };
+    void reset() {
+        for (auto& b : blocks) b.off = 0;
+        cur = 0;
+    }
+    Mark mark() const {
+        Mark k{cur, {}};
+        for (auto& b : blocks) k.offs.push_back(b.off);
+        return k;
+    }
+    void restore(const Mark& k) {
+        cur = k.cur;
+        for (size_t i = 0; i < blocks.size(); ++i) blocks[i].off = i < k.offs.size() ? k.offs[i] : 0;
+    }
+    template <class T>
+    T* get(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        while (cur < blocks.size() && blocks[cur].off + bytes > blocks[cur].cap) ++cur;
+        if (cur == blocks.size()) {
+            const size_t cap = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
+            void* p = nullptr;
+            HIP_CHECK(hipMalloc(&p, cap));
+            blocks.push_back({(char*)p, cap, 0});
+        }
+        T* r = (T*)(blocks[cur].p + blocks[cur].off);
+        blocks[cur].off += bytes;
+        return r;
+    }
+    void release() {
+        for (auto& b : blocks) (void)hipFree(b.p);
+        blocks.clear();
+        cur = 0;
+    }
+};
+
+struct q3asr_model {
+    q3asr_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    std::map<std::string, HostTensor> host;  // checkpoint tensors until finalize
+    std::vector<void*> owned;                // device allocations freed at destroy
+
+    MelTables mel;
+    bf16_t* zero_page = nullptr;
+    // encoder
+    float *conv1_w = nullptr, *conv1_b = nullptr, *conv2_b = nullptr, *conv3_b = nullptr;
+    LinearW conv2, conv3, conv_out, proj1, proj2;
+    float *proj1_b = nullptr, *proj2_b = nullptr, *ln_post_w = nullptr, *ln_post_b = nullptr, *pe_tab = nullptr;
+    std::vector<EncLayerW> enc;
+    int conv_f3 = 16;  // mel bins left after the three stride-2 convs
+    // decoder
+    LinearW embed;     // tied embedding / LM head
+    float* final_norm = nullptr;
+    std::vector<DecLayerW> dec;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_max_pos = 0;
+    BlockArena arena;  // per-call workspace
+
+    template <class T>
+    T* dalloc(size_t count) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, count * sizeof(T) > 0 ? count * sizeof(T) : 256));
+        owned.push_back(p);
+        return (T*)p;
+    }
+};
+
+void model_finalize(q3asr_model* m);
+void model_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_utt, int sample_rate, int audio_space,
+               float* mel_out, int t_stride, int32_t* n_frames, int out_space);
+void model_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t* n_frames, int n_utt, int mel_space,
+                  float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space);
+void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* res);
+int model_output_length(const q3asr_config& cfg, int frames);

@@ -1,0 +1,435 @@
+// Bandwidth-bound glue kernels of the transcription path (gfx950).
+#include "ops.h"
+
+namespace {
+
+__device__ __forceinline__ float dec_max(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// ------------------------------------------------------------------ conv2d1 + GELU
+// AudioEncoder.swift:379-380 on chunked input (:335-374); log-mel clamp/scale of
+// AudioPreprocessing.swift:269-288 applied while the 3 x 102 input patch is staged in LDS.
+__global__ __launch_bounds__(256) void conv1_kernel(Conv1Params p) {
+    __shared__ float patch[3][104];
+    const int oy = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const int u = p.chunk_utt[ch], t0 = p.chunk_t0[ch], clen = p.chunk_len[ch];
+    const float floor_v = p.normalized ? 0.f : dec_max(p.d_max[u]) - 8.0f;
+    for (int idx = tid; idx < 3 * 102; idx += 256) {
+        const int kh = idx / 102, j = idx % 102;
+        const int iy = 2 * oy - 1 + kh, ix = j - 1;
+        float v = 0.f;
+        if (iy >= 0 && iy < 128 && ix >= 0 && ix < clen) {
+            const float raw = p.mel[((int64_t)u * 128 + iy) * p.t_stride + t0 + ix];
+            v = p.normalized ? raw : (fmaxf(raw, floor_v) + 4.0f) / 4.0f;
+        }
+        patch[kh][j] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        float w[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] = p.w[c * 9 + k];
+        const float b = p.bias[c];
+        bf16_t* o = p.out + ((int64_t)(ch * 64 + oy) * 50) * p.C + c;
+        for (int ox = 0; ox < 50; ++ox) {
+            float acc = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], patch[kh][2 * ox + kw], acc);
+            o[(int64_t)ox * p.C] = f32_to_bf16(gelu_erf(acc + b));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm / RMSNorm (one wave per row)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, bf16_t* __restrict__ out, int rows,
+                                                        int d, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int d4 = d >> 2;
+    const float4* x4 = (const float4*)(x + (int64_t)row * d);
+    float4 v[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = (c < d4) ? x4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        if (c < d4) {
+            const float a = v[j].x - mean, bq = v[j].y - mean, cq = v[j].z - mean, dq = v[j].w - mean;
+            sq += a * a + bq * bq + cq * cq + dq * dq;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + eps);
+    bf16_t* o = out + (int64_t)row * d;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        if (c < d4) {
+            const float4 ww = ((const float4*)w)[c], bb = ((const float4*)b)[c];
+            const float y0 = (v[j].x - mean) * rstd * ww.x + bb.x, y1 = (v[j].y - mean) * rstd * ww.y + bb.y;
+            const float y2 = (v[j].z - mean) * rstd * ww.z + bb.z, y3 = (v[j].w - mean) * rstd * ww.w + bb.w;
+            *(uint2*)(o + 4 * c) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ w,
+                                                      bf16_t* __restrict__ out, int rows, int d, float eps,
+                                                      const int* __restrict__ rowidx, const float* __restrict__ slab,
+                                                      int nslab, int64_t slab_stride) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int64_t src = rowidx ? rowidx[row] : row;
+    const int d4 = d >> 2;
+    float4* x4 = (float4*)(x + src * d);
+    float4 v[8];
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < d4) {
+            v[j] = x4[c];
+            if (nslab > 0) {
+                for (int s = 0; s < nslab; ++s) {
+                    const float4 t = ((const float4*)(slab + s * slab_stride + src * d))[c];
+                    v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
+                }
+                x4[c] = v[j];
+            }
+        }
+        sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + eps);
+    bf16_t* o = out + (int64_t)row * d;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        if (c < d4) {
+            const float4 ww = ((const float4*)w)[c];
+            *(uint2*)(o + 4 * c) = make_uint2(pack_bf16x2(v[j].x * rstd * ww.x, v[j].y * rstd * ww.y),
+                                              pack_bf16x2(v[j].z * rstd * ww.z, v[j].w * rstd * ww.w));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ q/k norm + RoPE + KV append (one wave per head)
+__global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int slots = p.heads + 2 * p.kv_heads;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (int64_t)p.rows * slots) return;
+    const int row = (int)(gw / slots), slot = (int)(gw % slots);
+    const int u = p.row_utt ? p.row_utt[row] : row;
+    const int pos = p.row_pos ? p.row_pos[row] : p.cur_len[u];
+    bf16_t* src = p.qkv + (int64_t)row * p.ld + (int64_t)slot * 128;
+    const uint32_t raw = *(const uint32_t*)(src + 2 * lane);
+    if (slot >= p.heads + p.kv_heads) {  // V: cached as is
+        const int kvh = slot - p.heads - p.kv_heads;
+        *(uint32_t*)(p.vcache + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride + (int64_t)pos * 128 + 2 * lane) = raw;
+        return;
+    }
+    const bool is_q = slot < p.heads;
+    const float* w = is_q ? p.q_norm_w : p.k_norm_w;
+    const float x0 = __uint_as_float(raw << 16), x1 = __uint_as_float(raw & 0xffff0000u);
+    const float rstd = 1.0f / sqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.0f + p.eps);
+    const float y0 = x0 * rstd * w[2 * lane], y1 = x1 * rstd * w[2 * lane + 1];
+    float r0 = y0, r1 = y1;
+    const int pp = min(pos, p.max_pos - 1);
+    const float* ct = p.cos_tab + (int64_t)pp * p.half;
+    const float* st = p.sin_tab + (int64_t)pp * p.half;
+    if (p.interleaved) {  // pairs (2i, 2i+1): QuantizedTextDecoder.swift:245-252
+        if (lane < p.half) {
+            const float c = ct[lane], s = st[lane];
+            r0 = y0 * c - y1 * s;
+            r1 = y1 * c + y0 * s;
+        }
+    } else {              // rotate-half, pairs (i, i + half): :253-259
+        const int e0 = 2 * lane, h2 = p.half >> 1, rot = 2 * p.half;
+        const int partner = (e0 < p.half) ? lane + h2 : lane - h2;
+        const float p0 = __shfl(y0, partner & 63, 64), p1 = __shfl(y1, partner & 63, 64);
+        if (e0 < p.half) {
+            r0 = y0 * ct[e0] - p0 * st[e0];
+            r1 = y1 * ct[e0 + 1] - p1 * st[e0 + 1];
+        } else if (e0 < rot) {
+            const int j = e0 - p.half;
+            r0 = y0 * ct[j] + p0 * st[j];
+            r1 = y1 * ct[j + 1] + p1 * st[j + 1];
+        }
+    }
+    const uint32_t packed = pack_bf16x2(r0, r1);
+    if (is_q) {
+        *(uint32_t*)(src + 2 * lane) = packed;
+    } else {
+        const int kvh = slot - p.heads;
+        *(uint32_t*)(p.kcache + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride + (int64_t)pos * 128 + 2 * lane) = packed;
+    }
+}
+
+// ------------------------------------------------------------------ embedding gather / splice
+struct EmbedSrc {
+    const bf16_t* table;
+    const uint32_t* qw;
+    const bf16_t* qs;
+    const bf16_t* qb;
+    int qgroup, hidden;
+};
+// Four consecutive elements (i multiple of 4) of embedding row `id` as fp32.  MLX q4 rows are
+// dequantised as q * scale + bias and rounded to bf16, the dtype dequantized() returns
+// (QuantizedTextDecoder.swift:44-51).
+__device__ __forceinline__ float4 embed4(const EmbedSrc& e, int id, int i) {
+    if (e.table) {
+        const uint2 r = *(const uint2*)(e.table + (int64_t)id * e.hidden + i);
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                           __uint_as_float(r.y & 0xffff0000u));
+    }
+    const uint32_t code = e.qw[(int64_t)id * (e.hidden >> 3) + (i >> 3)] >> (4 * (i & 7));
+    const int g = e.hidden / e.qgroup;
+    const float s = bf16_to_f32(e.qs[(int64_t)id * g + i / e.qgroup]), b = bf16_to_f32(e.qb[(int64_t)id * g + i / e.qgroup]);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = bf16_to_f32(f32_to_bf16((float)((code >> (4 * j)) & 15u) * s + b));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// Population statistics of the prompt's text embeddings (all S rows, audio_pad rows included) and
+// of the audio embeddings (Qwen3ASR.swift:333-337).
+__global__ __launch_bounds__(256) void splice_stats_kernel(SpliceParams p, EmbedSrc e) {
+    __shared__ double sh[256];
+    const int u = blockIdx.x, part = blockIdx.y, nparts = gridDim.y, tid = threadIdx.x;
+    const int h4 = p.hidden >> 2;
+    double ts = 0, tq = 0, as = 0, aq = 0;
+    const int S = p.utt_rows[u], row0 = p.utt_row0[u];
+    for (int64_t idx = (int64_t)part * 256 + tid; idx < (int64_t)S * h4; idx += (int64_t)nparts * 256) {
+        const int r = (int)(idx / h4), c = (int)(idx % h4);
+        const float4 v = embed4(e, p.ids[row0 + r], 4 * c);
+        ts += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        tq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    const int N = p.utt_na[u];
+    const float4* a4 = (const float4*)(p.audio + (int64_t)p.utt_arow0[u] * p.hidden);
+    for (int64_t idx = (int64_t)part * 256 + tid; idx < (int64_t)N * h4; idx += (int64_t)nparts * 256) {
+        const float4 v = a4[idx];
+        as += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        aq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    ts = block_sum(ts, sh); tq = block_sum(tq, sh); as = block_sum(as, sh); aq = block_sum(aq, sh);
+    if (tid == 0) {
+        atomicAdd(p.stats + 4 * u + 0, ts);
+        atomicAdd(p.stats + 4 * u + 1, tq);
+        atomicAdd(p.stats + 4 * u + 2, as);
+        atomicAdd(p.stats + 4 * u + 3, aq);
+    }
+}
+
+__global__ __launch_bounds__(256) void splice_kernel(SpliceParams p, EmbedSrc e) {
+    const int h4 = p.hidden >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.rows * h4) return;
+    const int row = (int)(idx / h4), c = (int)(idx % h4);
+    const int u = p.row_utt[row];
+    const int r = row - p.utt_row0[u], a0 = p.utt_a0[u], na = p.utt_na[u];
+    float4 v;
+    if (r >= a0 && r < a0 + na) {
+        float scale = 1.0f;
+        if (p.embed_scale) {  // Qwen3ASR.swift:331-350
+            const double tn = (double)p.utt_rows[u] * p.hidden, an = (double)na * p.hidden;
+            const double tm = p.stats[4 * u] / tn, am = p.stats[4 * u + 2] / an;
+            const float tstd = (float)sqrt(fmax(p.stats[4 * u + 1] / tn - tm * tm, 0.0));
+            const float astd = (float)sqrt(fmax(p.stats[4 * u + 3] / an - am * am, 0.0));
+            if (astd > 0.f) scale = tstd / astd;
+        }
+        v = ((const float4*)(p.audio + (int64_t)(p.utt_arow0[u] + r - a0) * p.hidden))[c];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    } else {
+        v = embed4(e, p.ids[row], 4 * c);
+    }
+    ((float4*)(p.hidden_out + (int64_t)row * p.hidden))[c] = v;
+}
+
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict__ tok, int B, EmbedSrc e, float* __restrict__ out) {
+    const int h4 = e.hidden >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * h4) return;
+    const int u = (int)(idx / h4), c = (int)(idx % h4);
+    ((float4*)(out + (int64_t)u * e.hidden))[c] = embed4(e, tok[u], 4 * c);
+}
+
+// ------------------------------------------------------------------ argmax
+__device__ __forceinline__ void amax_combine(float& bv, int& bi, float v, int i) {
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+__device__ __forceinline__ void amax_block(float bv, int bi, int* out) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x;
+    sv[tid] = bv; si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            float v = sv[tid]; int i = si[tid];
+            amax_combine(v, i, sv[tid + o], si[tid + o]);
+            sv[tid] = v; si[tid] = i;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *out = si[0];
+}
+__global__ __launch_bounds__(256) void argmax_reduce_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
+                                                            int* __restrict__ out) {
+    const int row = blockIdx.x;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < nparts; k += 256) amax_combine(bv, bi, pv[(int64_t)row * nparts + k], pi[(int64_t)row * nparts + k]);
+    amax_block(bv, bi, out + row);
+}
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int n, int* __restrict__ out) {
+    const int row = blockIdx.x;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < n; k += 256) amax_combine(bv, bi, x[(int64_t)row * n + k], k);
+    amax_block(bv, bi, out + row);
+}
+
+// ------------------------------------------------------------------ greedy bookkeeping + stop rules
+constexpr int TOK_IM_START = 151644, TOK_IM_END = 151645, TOK_ENDOFTEXT = 151643;
+constexpr int TOK_AUDIO_START = 151669, TOK_AUDIO_END = 151670, TOK_AUDIO_PAD = 151676, TOK_ASR_TEXT = 151704;
+
+__global__ __launch_bounds__(256) void step_kernel(StepParams p) {
+    __shared__ int active;
+    if (threadIdx.x == 0) active = 0;
+    __syncthreads();
+    for (int u = threadIdx.x; u < p.B; u += 256) {
+        if (!p.done[u]) {
+            const int tok = p.argmax[u];
+            int* toks = p.tokens + (int64_t)u * p.max_tokens;
+            int n = p.ntok[u];
+            toks[n++] = tok;
+            p.ntok[u] = n;
+            bool stop = false;
+            if (p.stop_rules) {
+                const int seen = p.seen_asr[u];
+                // breaks evaluated right after the append: Qwen3ASR.swift:597-627
+                if (tok == TOK_IM_START || tok == TOK_AUDIO_START || tok == TOK_AUDIO_END || tok == TOK_AUDIO_PAD) stop = true;
+                if (!stop && seen && n >= 32) {
+                    int run = 0;
+                    for (int i = n - 1; i >= 0 && toks[i] == tok; --i) ++run;
+                    if (run >= 16) stop = true;
+                }
+                if (!stop && seen && n >= 64) {
+                    int uniq[5], nu = 0;
+                    for (int i = n - 64; i < n && nu <= 4; ++i) {
+                        bool found = false;
+                        for (int k = 0; k < nu; ++k) found |= (uniq[k] == toks[i]);
+                        if (!found) uniq[nu++] = toks[i];
+                    }
+                    if (nu <= 4) stop = true;
+                }
+                // checks made at the top of the next iteration: :571-578
+                if (!stop) {
+                    if (tok == TOK_IM_END || tok == TOK_ENDOFTEXT) stop = true;
+                    else if (tok == TOK_ASR_TEXT) p.seen_asr[u] = 1;
+                }
+            }
+            if (n >= p.max_tokens) stop = true;
+            p.next_tok[u] = p.forced ? p.forced[(int64_t)u * p.max_tokens + n - 1] : tok;
+            if (stop) p.done[u] = 1;
+            else atomicAdd(&active, 1);
+            if (p.advance) p.cur_len[u] += 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *p.n_active = active;
+}
+
+}  // namespace
+
+void launch_conv1(const Conv1Params& p, hipStream_t s) {
+    if (p.n_chunks <= 0) return;
+    hipLaunchKernelGGL(conv1_kernel, dim3(64, p.n_chunks), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_layernorm(const float* x, const float* w, const float* b, bf16_t* out, int rows, int d, float eps, hipStream_t s) {
+    if (rows <= 0) return;
+    Q3_REQUIRE(d % 4 == 0 && d <= 2048, "layernorm: width must be a multiple of 4 and <= 2048");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, out, rows, d, eps);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_rmsnorm(float* x, const float* w, bf16_t* out, int rows, int d, float eps, const int* rowidx, const float* slab,
+                    int nslab, int64_t slab_stride, hipStream_t s) {
+    if (rows <= 0) return;
+    Q3_REQUIRE(d % 4 == 0 && d <= 2048, "rmsnorm: width must be a multiple of 4 and <= 2048");
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, out, rows, d, eps, rowidx, slab, nslab,
+                       slab_stride);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_rope(const RopeParams& p, hipStream_t s) {
+    if (p.rows <= 0) return;
+    Q3_REQUIRE(p.half % 2 == 0 && p.half <= 64, "rope: rotary half-dim must be even and <= 64");
+    const int64_t waves = (int64_t)p.rows * (p.heads + 2 * p.kv_heads);
+    hipLaunchKernelGGL(rope_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_splice(const SpliceParams& p, hipStream_t s) {
+    if (p.rows <= 0) return;
+    Q3_REQUIRE(p.hidden % 8 == 0, "splice: hidden must be a multiple of 8");
+    EmbedSrc e{p.table, p.qw, p.qs, p.qb, p.qgroup, p.hidden};
+    if (p.embed_scale) {
+        hipLaunchKernelGGL(splice_stats_kernel, dim3(p.B, 8), dim3(256), 0, s, p, e);
+        HIP_CHECK(hipGetLastError());
+    }
+    const int64_t n = (int64_t)p.rows * (p.hidden / 4);
+    hipLaunchKernelGGL(splice_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, e);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_embed_tokens(const int* tok, int B, int hidden, const bf16_t* table, const uint32_t* qw, const bf16_t* qs,
+                         const bf16_t* qb, int qgroup, float* out, hipStream_t s) {
+    if (B <= 0) return;
+    EmbedSrc e{table, qw, qs, qb, qgroup, hidden};
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv((int64_t)B * (hidden / 4), 256)), dim3(256), 0, s, tok, B, e, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_argmax_reduce(const float* part_val, const int* part_idx, int nparts, int rows, int* out, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(argmax_reduce_kernel, dim3(rows), dim3(256), 0, s, part_val, part_idx, nparts, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_argmax_rows(const float* logits, int rows, int n, int* out, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, s, logits, n, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_step(const StepParams& p, hipStream_t s) {
+    if (p.B <= 0) return;
+    hipLaunchKernelGGL(step_kernel, dim3(1), dim3(256), 0, s, p);
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,644 @@
+// Batched transcription pipeline: mel -> encoder -> prompt splice -> prefill -> greedy decode.
+// Host control flow of Qwen3ASRModel.transcribe / _generateText (reference: Qwen3ASR.swift:60-145,
+// 170-632) re-designed for many utterances at once on one GPU: utterances are sorted by length,
+// processed in groups of cfg.max_batch, packed without padding (rows = sum of lengths) through
+// the GEMMs, and decoded together with per-utterance KV-cache lengths; the stop rules run on the
+// device and the host only polls a counter every few steps.
+#include "model.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <numeric>
+
+namespace {
+
+constexpr int TOK_IM_START = 151644, TOK_IM_END = 151645, TOK_AUDIO_START = 151669, TOK_AUDIO_END = 151670;
+constexpr int TOK_AUDIO_PAD = 151676, TOK_ASR_TEXT = 151704, TOK_NEWLINE = 198, TOK_SYSTEM = 8948, TOK_USER = 872;
+constexpr int TOK_ASSISTANT = 77091;
+constexpr int ENC_CHUNK_BUDGET = 960;   // chunks per encoder pass (32 clips of 30 s)
+constexpr int PREFILL_ROW_BUDGET = 32768;
+constexpr int POLL_STEPS = 8;
+
+inline int conv_len(int n) { return (n - 1) / 2 + 1; }
+inline int feat_len(int clen) { return conv_len(conv_len(conv_len(clen))); }
+
+struct Ctx {
+    q3asr_model* m;
+    hipStream_t s;
+    std::deque<std::vector<uint8_t>> keep;  // host staging kept alive until the call's last sync
+    template <class T>
+    T* get(size_t n) { return m->arena.get<T>(n); }
+    template <class T>
+    T* up(const std::vector<T>& v) {
+        T* d = get<T>(v.size());
+        if (!v.empty()) {
+            keep.emplace_back((const uint8_t*)v.data(), (const uint8_t*)v.data() + v.size() * sizeof(T));
+            HIP_CHECK(hipMemcpyAsync(d, keep.back().data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        }
+        return d;
+    }
+};
+
+GemmParams gp(const Ctx& c, const bf16_t* A, int64_t lda, const LinearW& W, int M) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = W.w; p.qscales = W.scales; p.qbiases = W.biases; p.qgroup = c.m->cfg.group_size;
+    p.M = M; p.N = W.N; p.K = W.K; p.zero = c.m->zero_page;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------ mel
+struct MelRun {
+    float* raw = nullptr;      // [b][128][t_stride] raw log10 mel
+    unsigned* dmax = nullptr;  // [b]
+    int* d_frames = nullptr;   // [b]
+    int t_stride = 0;
+    std::vector<int> frames;   // frames returned per utterance
+    std::vector<int64_t> n16;  // samples at 16 kHz
+};
+
+// src_off / src_len: position of every utterance in `audio` (input sample rate).
+MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>& src_off, const std::vector<int64_t>& src_len,
+               int sample_rate, int t_stride) {
+    const int b = (int)src_off.size();
+    MelRun r;
+    r.n16.resize(b);
+    r.frames.resize(b);
+    const double ratio = 16000.0 / (double)sample_rate;
+    int64_t tot_in = 0, tot16 = 0;
+    for (int u = 0; u < b; ++u) {
+        // resample output length: AudioPreprocessing.swift:348-349
+        r.n16[u] = sample_rate == 16000 ? src_len[u] : (int64_t)((double)src_len[u] * ratio);
+        r.frames[u] = mel_frames_out(r.n16[u]);
+        tot_in += src_len[u];
+        tot16 += r.n16[u];
+    }
+    // stage the input on the device
+    const float* d_in = audio;
+    std::vector<int64_t> in_off = src_off;
+    if (space == Q3ASR_HOST) {
+        float* buf = c.get<float>(tot_in);
+        int64_t o = 0;
+        for (int u = 0; u < b; ++u) {
+            if (src_len[u]) HIP_CHECK(hipMemcpyAsync(buf + o, audio + src_off[u], src_len[u] * 4, hipMemcpyHostToDevice, c.s));
+            in_off[u] = o;
+            o += src_len[u];
+        }
+        d_in = buf;
+    }
+    const float* d16 = d_in;
+    std::vector<int64_t> off16 = in_off;
+    if (sample_rate != 16000) {
+        float* buf = c.get<float>(tot16);
+        int64_t o = 0;
+        for (int u = 0; u < b; ++u) {
+            launch_resample(d_in + in_off[u], src_len[u], buf + o, r.n16[u], ratio, c.s);
+            off16[u] = o;
+            o += r.n16[u];
+        }
+        d16 = buf;
+    }
+    std::vector<int> tile_utt, tile_f0;
+    int tmax = 1;
+    for (int u = 0; u < b; ++u) {
+        const int total = mel_frames_total(r.n16[u]);
+        for (int f0 = 0; f0 < total; f0 += MEL_TILE_FRAMES) { tile_utt.push_back(u); tile_f0.push_back(f0); }
+        tmax = std::max(tmax, r.frames[u]);
+    }
+    r.t_stride = t_stride > 0 ? t_stride : ((tmax + 3) & ~3);
+    Q3_REQUIRE(r.t_stride >= tmax, "mel: t_stride is smaller than the longest utterance's frame count");
+    r.raw = c.get<float>((size_t)b * MEL_NMELS * r.t_stride);
+    r.dmax = c.get<unsigned>(b);
+    HIP_CHECK(hipMemsetAsync(r.dmax, 0, (size_t)b * 4, c.s));
+    r.d_frames = c.up(r.frames);
+    launch_mel(c.m->mel, d16, c.up(off16), c.up(r.n16), c.up(tile_utt), c.up(tile_f0), (int)tile_utt.size(), r.raw, r.t_stride,
+               r.dmax, c.s);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ encoder
+// Encodes utterances whose (raw or normalised) mel rows live in `mel`; writes packed fp32
+// embeddings [sum N][out_dim] to `out` in the given order and returns the token counts.
+std::vector<int> run_encoder(Ctx& c, const float* mel, int t_stride, const unsigned* dmax, int normalized,
+                             const std::vector<int>& frames, float* out) {
+    q3asr_model* m = c.m;
+    const q3asr_config& cfg = m->cfg;
+    const int b = (int)frames.size(), d = cfg.enc_d_model, C = cfg.conv_channels, F3 = m->conv_f3;
+    const int chunk = cfg.n_window * 2;
+    Q3_REQUIRE(chunk == 100 && cfg.n_mels == 128, "encoder: kernels are built for 128 mel bins and 100-frame chunks");
+    std::vector<int> ntok(b);
+    for (int u = 0; u < b; ++u) ntok[u] = model_output_length(cfg, frames[u]);
+    int64_t out_row = 0;
+    int u0 = 0;
+    while (u0 < b) {
+        // ---- group of utterances within the chunk budget ----
+        int u1 = u0, nch = 0;
+        while (u1 < b) {
+            const int k = (frames[u1] + chunk - 1) / chunk;
+            if (u1 > u0 && nch + k > ENC_CHUNK_BUDGET) break;
+            nch += k;
+            ++u1;
+        }
+        const auto mark = m->arena.mark();
+        std::vector<int> ch_utt, ch_t0, ch_len, win1, win2, rowmap3, rowmap_tok;
+        std::vector<AttnSeq> seqs;
+        std::vector<AttnTile> tiles;
+        int ntok_g = 0;
+        for (int u = u0; u < u1; ++u) {
+            const int T = frames[u], k = (T + chunk - 1) / chunk;
+            // chunk lengths and the common padded length: AudioEncoder.swift:335-374
+            const int last = (T % chunk == 0) ? chunk : T % chunk;
+            const int wp = k > 1 ? chunk : last;
+            const int w1 = conv_len(wp), w2 = conv_len(w1);
+            const int tok0 = ntok_g;
+            for (int i = 0; i < k; ++i) {
+                const int clen = (i == k - 1) ? last : chunk;
+                ch_utt.push_back(u); ch_t0.push_back(i * chunk); ch_len.push_back(clen);
+                win1.push_back(w1); win2.push_back(w2);
+                const int fl = feat_len(clen);  // valid tokens of the chunk: :416-423
+                for (int t = 0; t < 13; ++t) rowmap_tok.push_back(t < fl ? ntok_g + t : -1);
+                ntok_g += fl;
+            }
+            Q3_REQUIRE(ntok_g - tok0 == ntok[u], "encoder: token count mismatch");
+            // attention windows: :441-466
+            if (k > 0) {
+                int maxfl = 0;
+                for (int i = 0; i < k; ++i) maxfl = std::max(maxfl, feat_len(i == k - 1 ? last : chunk));
+                const int window = maxfl * (cfg.n_window_infer / chunk);
+                for (int st = 0; st < ntok[u]; st += window) {
+                    const int len = std::min(window, ntok[u] - st);
+                    seqs.push_back({tok0 + st, len, (int64_t)(tok0 + st) * 3 * d});
+                    for (int q0 = 0; q0 < len; q0 += 64) tiles.push_back({(int)seqs.size() - 1, q0});
+                }
+            }
+        }
+        const int nc = (int)ch_utt.size();
+        if (nc > 0 && ntok_g > 0) {
+            for (int ch = 0; ch < nc; ++ch)
+                for (int oy = 0; oy < F3; ++oy)
+                    for (int ox = 0; ox < 13; ++ox) rowmap3.push_back((ch * 13 + ox) * F3 + oy);
+            bf16_t* c1 = c.get<bf16_t>((size_t)nc * 64 * 50 * C);
+            bf16_t* c2 = c.get<bf16_t>((size_t)nc * 32 * 25 * C);
+            bf16_t* c3 = c.get<bf16_t>((size_t)nc * 13 * F3 * C);
+            float* h = c.get<float>((size_t)ntok_g * d);
+            bf16_t* xn = c.get<bf16_t>((size_t)ntok_g * d);
+            bf16_t* qkv = c.get<bf16_t>((size_t)ntok_g * 3 * d);
+            bf16_t* att = c.get<bf16_t>((size_t)ntok_g * d);
+            bf16_t* ffn = c.get<bf16_t>((size_t)ntok_g * cfg.enc_ffn);
+            const int* d_win1 = c.up(win1);
+            const int* d_win2 = c.up(win2);
+            const int* d_rowmap3 = c.up(rowmap3);
+            const int* d_rowmap_tok = c.up(rowmap_tok);
+            const AttnSeq* d_seqs = c.up(seqs);
+            const AttnTile* d_tiles = c.up(tiles);
+
+            Conv1Params p1{mel, t_stride, dmax, c.up(ch_utt), c.up(ch_t0), c.up(ch_len), nc, m->conv1_w, m->conv1_b, C, c1, normalized};
+            launch_conv1(p1, c.s);
+            {   // conv2d2 + GELU: implicit GEMM, rows (chunk, 32, 25)
+                GemmParams p = gp(c, c1, 0, m->conv2, nc * 32 * 25);
+                p.Hin = 64; p.Win = 50; p.Cin = C; p.Hout = 32; p.Wout = 25; p.win_valid = d_win1;
+                p.bias = m->conv2_b; p.act = 1; p.out = c2; p.ldo = C;
+                launch_gemm(p, A_CONV3X3S2, OUT_BF16, W_BF16, -1, c.s);
+            }
+            {   // conv2d3 + GELU, rows (chunk, 16, 13) stored as [chunk][t][f][c]
+                GemmParams p = gp(c, c2, 0, m->conv3, nc * F3 * 13);
+                p.Hin = 32; p.Win = 25; p.Cin = C; p.Hout = F3; p.Wout = 13; p.win_valid = d_win2;
+                p.bias = m->conv3_b; p.act = 1; p.out = c3; p.ldo = C; p.rowmap = d_rowmap3;
+                launch_gemm(p, A_CONV3X3S2, OUT_BF16, W_BF16, -1, c.s);
+            }
+            {   // conv_out (no bias) + per-chunk sinusoid + valid-token packing: :401-436
+                GemmParams p = gp(c, c3, (int64_t)F3 * C, m->conv_out, nc * 13);
+                p.rowtab = m->pe_tab; p.rowtab_period = 13; p.rowmap = d_rowmap_tok; p.out = h; p.ldo = d;
+                launch_gemm(p, A_PLAIN, OUT_F32, W_BF16, -1, c.s);
+            }
+            for (int l = 0; l < cfg.enc_layers; ++l) {
+                const EncLayerW& L = m->enc[l];
+                launch_layernorm(h, L.ln1_w, L.ln1_b, xn, ntok_g, d, cfg.ln_eps, c.s);
+                {
+                    GemmParams p = gp(c, xn, d, L.qkv, ntok_g);
+                    p.bias = L.qkv_b; p.out = qkv; p.ldo = 3 * d;
+                    launch_gemm(p, A_PLAIN, OUT_BF16, W_BF16, -1, c.s);
+                }
+                FlashParams fp{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, d / cfg.enc_heads, att, d, d_seqs, d_tiles, (int)tiles.size(),
+                               cfg.enc_heads, 1, 1.0f / sqrtf((float)(d / cfg.enc_heads)), 0};
+                launch_flash_attn(fp, d / cfg.enc_heads, c.s);
+                {
+                    GemmParams p = gp(c, att, d, L.out, ntok_g);
+                    p.bias = L.out_b; p.out = h; p.ldo = d;
+                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, W_BF16, -1, c.s);
+                }
+                launch_layernorm(h, L.ln2_w, L.ln2_b, xn, ntok_g, d, cfg.ln_eps, c.s);
+                {
+                    GemmParams p = gp(c, xn, d, L.fc1, ntok_g);
+                    p.bias = L.fc1_b; p.act = 1; p.out = ffn; p.ldo = cfg.enc_ffn;
+                    launch_gemm(p, A_PLAIN, OUT_BF16, W_BF16, -1, c.s);
+                }
+                {
+                    GemmParams p = gp(c, ffn, cfg.enc_ffn, L.fc2, ntok_g);
+                    p.bias = L.fc2_b; p.out = h; p.ldo = d;
+                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, W_BF16, -1, c.s);
+                }
+            }
+            launch_layernorm(h, m->ln_post_w, m->ln_post_b, xn, ntok_g, d, cfg.ln_eps, c.s);
+            {
+                GemmParams p = gp(c, xn, d, m->proj1, ntok_g);
+                p.bias = m->proj1_b; p.act = 1; p.out = att; p.ldo = d;
+                launch_gemm(p, A_PLAIN, OUT_BF16, W_BF16, -1, c.s);
+            }
+            {
+                GemmParams p = gp(c, att, d, m->proj2, ntok_g);
+                p.bias = m->proj2_b; p.out = out + out_row * cfg.enc_out_dim; p.ldo = cfg.enc_out_dim;
+                launch_gemm(p, A_PLAIN, OUT_F32, W_BF16, -1, c.s);
+            }
+        }
+        out_row += ntok_g;
+        m->arena.restore(mark);
+        u0 = u1;
+    }
+    return ntok;
+}
+
+}  // namespace
+
+int model_output_length(const q3asr_config& cfg, int frames) {
+    // getOutputLength: AudioEncoder.swift:254-270
+    const int chunk = cfg.n_window * 2, rem = frames % chunk;
+    return (frames / chunk) * 13 + (rem > 0 ? std::max(feat_len(rem), 1) : 0);
+}
+
+void model_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_utt, int sample_rate, int audio_space,
+               float* mel_out, int t_stride, int32_t* n_frames, int out_space) {
+    Q3_REQUIRE(n_utt > 0 && audio && offsets && mel_out && n_frames, "mel: null argument or empty batch");
+    Q3_REQUIRE(sample_rate > 0, "mel: sample rate must be positive");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    Ctx c{m, m->stream, {}};
+    std::vector<int64_t> off(n_utt), len(n_utt);
+    for (int u = 0; u < n_utt; ++u) {
+        off[u] = offsets[u];
+        len[u] = offsets[u + 1] - offsets[u];
+        Q3_REQUIRE(len[u] >= 0, "mel: offsets must be non-decreasing");
+    }
+    MelRun r = run_mel(c, audio, audio_space, off, len, sample_rate, t_stride);
+    launch_mel_normalize(r.raw, n_utt, r.t_stride, r.d_frames, r.dmax, c.s);
+    const size_t bytes = (size_t)n_utt * MEL_NMELS * r.t_stride * 4;
+    HIP_CHECK(hipMemcpyAsync(mel_out, r.raw, bytes, out_space == Q3ASR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c.s));
+    HIP_CHECK(hipStreamSynchronize(c.s));
+    for (int u = 0; u < n_utt; ++u) n_frames[u] = r.frames[u];
+}
+
+void model_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t* n_frames, int n_utt, int mel_space,
+                  float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space) {
+    Q3_REQUIRE(m->finalized, "encode: weights not finalized");
+    Q3_REQUIRE(n_utt > 0 && mel && n_frames && embeds_out && cu_tokens, "encode: null argument or empty batch");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    Ctx c{m, m->stream, {}};
+    std::vector<int> frames(n_frames, n_frames + n_utt);
+    int64_t total = 0;
+    cu_tokens[0] = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        Q3_REQUIRE(frames[u] >= 0 && frames[u] <= t_stride && frames[u] <= MEL_MAX_FRAMES, "encode: frame count out of range");
+        total += model_output_length(m->cfg, frames[u]);
+        cu_tokens[u + 1] = (int32_t)total;
+    }
+    Q3_REQUIRE(total <= out_rows_capacity, "encode: output buffer too small");
+    const float* d_mel = mel;
+    if (mel_space == Q3ASR_HOST) {
+        float* buf = c.get<float>((size_t)n_utt * MEL_NMELS * t_stride);
+        HIP_CHECK(hipMemcpyAsync(buf, mel, (size_t)n_utt * MEL_NMELS * t_stride * 4, hipMemcpyHostToDevice, c.s));
+        d_mel = buf;
+    }
+    float* d_out = c.get<float>((size_t)std::max<int64_t>(total, 1) * m->cfg.enc_out_dim);
+    run_encoder(c, d_mel, t_stride, nullptr, 1, frames, d_out);
+    if (total > 0)
+        HIP_CHECK(hipMemcpyAsync(embeds_out, d_out, (size_t)total * m->cfg.enc_out_dim * 4,
+                                 out_space == Q3ASR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c.s));
+    HIP_CHECK(hipStreamSynchronize(c.s));
+}
+
+// ------------------------------------------------------------------------------------------ transcribe
+namespace {
+
+struct Events {
+    hipEvent_t e[5];
+    Events() { for (auto& x : e) HIP_CHECK(hipEventCreate(&x)); }
+    ~Events() { for (auto& x : e) (void)hipEventDestroy(x); }
+};
+
+void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const std::vector<int>& idx,
+                      const std::vector<int64_t>& tap_a_off, const std::vector<int64_t>& tap_s_off) {
+    q3asr_model* m = c.m;
+    const q3asr_config& cfg = m->cfg;
+    const int b = (int)idx.size(), H = cfg.hidden, hd = cfg.head_dim, nh = cfg.heads, nkv = cfg.kv_heads;
+    const int QKV = (nh + 2 * nkv) * hd, max_tokens = req->max_tokens;
+    const GemmWFmt wf = cfg.weight_format == 1 ? W_Q4 : W_BF16;
+    Events ev;
+    HIP_CHECK(hipEventRecord(ev.e[0], c.s));
+
+    // ---- mel ----
+    std::vector<int64_t> off(b), len(b);
+    for (int i = 0; i < b; ++i) {
+        off[i] = req->offsets[idx[i]];
+        len[i] = req->offsets[idx[i] + 1] - off[i];
+    }
+    MelRun mel = run_mel(c, req->audio, req->audio_space, off, len, req->sample_rate, 0);
+    HIP_CHECK(hipEventRecord(ev.e[1], c.s));
+
+    // ---- encoder ----
+    std::vector<int> ntok(b);
+    int64_t tot_a = 0;
+    for (int i = 0; i < b; ++i) {
+        ntok[i] = model_output_length(cfg, mel.frames[i]);
+        tot_a += ntok[i];
+        res->audio_seconds += (double)std::min<int64_t>(mel.n16[i], (int64_t)MEL_MAX_FRAMES * MEL_HOP) / 16000.0;
+    }
+    float* audio_emb = c.get<float>((size_t)std::max<int64_t>(tot_a, 1) * cfg.enc_out_dim);
+    run_encoder(c, mel.raw, mel.t_stride, mel.dmax, 0, mel.frames, audio_emb);
+    HIP_CHECK(hipEventRecord(ev.e[2], c.s));
+
+    // ---- prompt (Qwen3ASR.swift:282-317) ----
+    std::vector<int> ids, row_utt, row_pos, utt_row0(b), utt_rows(b), utt_a0(b), utt_na(b), utt_arow0(b), last_rows(b), seen0(b, 0);
+    int arow = 0, cap = 0;
+    for (int i = 0; i < b; ++i) {
+        const int u = idx[i];
+        utt_row0[i] = (int)ids.size();
+        const int head[] = {TOK_IM_START, TOK_SYSTEM, TOK_NEWLINE, TOK_IM_END, TOK_NEWLINE, TOK_IM_START, TOK_USER, TOK_NEWLINE, TOK_AUDIO_START};
+        for (int t : head) ids.push_back(t);
+        utt_a0[i] = 9;
+        for (int k = 0; k < ntok[i]; ++k) ids.push_back(TOK_AUDIO_PAD);
+        const int tail[] = {TOK_AUDIO_END, TOK_IM_END, TOK_NEWLINE, TOK_IM_START, TOK_ASSISTANT, TOK_NEWLINE};
+        for (int t : tail) ids.push_back(t);
+        if (req->lang_ids && req->lang_offsets && req->lang_offsets[u + 1] > req->lang_offsets[u]) {
+            bool has = false;
+            for (int k = req->lang_offsets[u]; k < req->lang_offsets[u + 1]; ++k) {
+                Q3_REQUIRE(req->lang_ids[k] >= 0 && req->lang_ids[k] < cfg.vocab, "transcribe: language prefix id out of range");
+                ids.push_back(req->lang_ids[k]);
+                has |= req->lang_ids[k] == TOK_ASR_TEXT;
+            }
+            if (!has) ids.push_back(TOK_ASR_TEXT);
+            seen0[i] = 1;  // :565-566
+        }
+        utt_rows[i] = (int)ids.size() - utt_row0[i];
+        utt_na[i] = ntok[i];
+        utt_arow0[i] = arow;
+        arow += ntok[i];
+        for (int k = 0; k < utt_rows[i]; ++k) { row_utt.push_back(i); row_pos.push_back(k); }
+        last_rows[i] = (int)ids.size() - 1;
+        cap = std::max(cap, utt_rows[i] + max_tokens);
+        if (res->n_audio_tokens) res->n_audio_tokens[u] = ntok[i];
+    }
+    const int R = (int)ids.size();
+    Q3_REQUIRE(cap <= m->rope_max_pos, "transcribe: prompt + max_tokens exceeds the RoPE table");
+    Q3_REQUIRE(cfg.enc_out_dim == H, "transcribe: encoder output dim must equal decoder hidden size");
+
+    // ---- buffers ----
+    const int64_t head_stride = (int64_t)cap * hd, utt_stride = head_stride * nkv, layer_stride = utt_stride * b;
+    bf16_t* kc = c.get<bf16_t>((size_t)layer_stride * cfg.layers);
+    bf16_t* vc = c.get<bf16_t>((size_t)layer_stride * cfg.layers);
+    float* hid = c.get<float>((size_t)R * H);
+    const int* d_ids = c.up(ids);
+    const int* d_row_utt = c.up(row_utt);
+    const int* d_row_pos = c.up(row_pos);
+    const int* d_row0 = c.up(utt_row0);
+    const int* d_rows = c.up(utt_rows);
+    const int* d_last = c.up(last_rows);
+    double* stats = c.get<double>((size_t)b * 4);
+    HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)b * 32, c.s));
+    int* st_tokens = c.get<int>((size_t)b * max_tokens);
+    int* st_ntok = c.get<int>(b);
+    int* st_done = c.get<int>(b);
+    int* st_seen = c.up(seen0);
+    int* st_next = c.get<int>(b);
+    int* st_len = c.up(utt_rows);
+    int* st_active = c.get<int>(64);
+    int* st_argmax = c.get<int>(b);
+    HIP_CHECK(hipMemsetAsync(st_ntok, 0, (size_t)b * 4, c.s));
+    HIP_CHECK(hipMemsetAsync(st_done, 0, (size_t)b * 4, c.s));
+    const int* d_forced = nullptr;
+    if (req->forced_tokens) {
+        std::vector<int> f((size_t)b * max_tokens);
+        for (int i = 0; i < b; ++i) memcpy(&f[(size_t)i * max_tokens], req->forced_tokens + (size_t)idx[i] * max_tokens, (size_t)max_tokens * 4);
+        d_forced = c.up(f);
+    }
+    const int head_tile = 0;
+    const int nparts = gemm_argmax_parts(cfg.vocab, head_tile);
+    float* part_val = c.get<float>((size_t)b * nparts);
+    int* part_idx = c.get<int>((size_t)b * nparts);
+    bf16_t* x_last = c.get<bf16_t>((size_t)b * H);
+    float* logits = req->tap_logits && req->tap_steps > 0 ? c.get<float>((size_t)b * cfg.vocab) : nullptr;
+
+    const bool qemb = cfg.weight_format == 1;
+    SpliceParams sp{d_ids, d_row_utt, d_row0, d_rows, c.up(utt_a0), c.up(utt_na), c.up(utt_arow0), R, b, H,
+                    qemb ? nullptr : (const bf16_t*)m->embed.w, qemb ? (const uint32_t*)m->embed.w : nullptr, m->embed.scales,
+                    m->embed.biases, cfg.group_size, audio_emb, stats, cfg.embed_scale, hid};
+    launch_splice(sp, c.s);
+    if (req->tap_audio_embeds || req->tap_inputs_embeds) {
+        for (int i = 0; i < b; ++i) {
+            if (req->tap_audio_embeds && ntok[i])
+                HIP_CHECK(hipMemcpyAsync(req->tap_audio_embeds + tap_a_off[idx[i]] * H, audio_emb + (int64_t)utt_arow0[i] * H,
+                                         (size_t)ntok[i] * H * 4, hipMemcpyDeviceToHost, c.s));
+            if (req->tap_inputs_embeds)
+                HIP_CHECK(hipMemcpyAsync(req->tap_inputs_embeds + tap_s_off[idx[i]] * H, hid + (int64_t)utt_row0[i] * H,
+                                         (size_t)utt_rows[i] * H * 4, hipMemcpyDeviceToHost, c.s));
+        }
+    }
+
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int half = std::min(cfg.rotary_dim, hd) / 2;
+
+    // LM head on `rows` normalised rows -> st_argmax (and optional logits tap)
+    auto lm_head = [&](const bf16_t* x, int rows, int step) {
+        const bool tap = logits && step < req->tap_steps;
+        GemmParams p = gp(c, x, H, m->embed, rows);
+        if (tap) {
+            p.out = logits; p.ldo = cfg.vocab;
+            launch_gemm(p, A_PLAIN, OUT_F32, wf, head_tile, c.s);
+            launch_argmax_rows(logits, rows, cfg.vocab, st_argmax, c.s);
+            for (int i = 0; i < rows; ++i)
+                HIP_CHECK(hipMemcpyAsync(req->tap_logits + ((size_t)idx[i] * req->tap_steps + step) * cfg.vocab,
+                                         logits + (size_t)i * cfg.vocab, (size_t)cfg.vocab * 4, hipMemcpyDeviceToHost, c.s));
+        } else {
+            p.part_val = part_val; p.part_idx = part_idx; p.nparts = nparts;
+            launch_gemm(p, A_PLAIN, OUT_ARGMAX, wf, head_tile, c.s);
+            launch_argmax_reduce(part_val, part_idx, nparts, rows, st_argmax, c.s);
+        }
+    };
+    auto step = [&](int advance) {
+        StepParams sp2{st_argmax, st_tokens, st_ntok, st_done, st_seen, st_next, st_len, st_active, d_forced, b, max_tokens, advance,
+                       req->forced_tokens ? 0 : req->stop_rules};
+        launch_step(sp2, c.s);
+    };
+
+    // ---- prefill (QuantizedTextDecoder.swift:384-446 over the packed prompts) ----
+    {
+        const auto mark = m->arena.mark();
+        bf16_t* xn = c.get<bf16_t>((size_t)R * H);
+        bf16_t* qkv = c.get<bf16_t>((size_t)R * QKV);
+        bf16_t* att = c.get<bf16_t>((size_t)R * nh * hd);
+        bf16_t* act = c.get<bf16_t>((size_t)R * cfg.inter);
+        std::vector<AttnSeq> seqs;
+        std::vector<AttnTile> tiles;
+        for (int i = 0; i < b; ++i) {
+            seqs.push_back({utt_row0[i], utt_rows[i], (int64_t)i * utt_stride});
+            for (int q0 = 0; q0 < utt_rows[i]; q0 += 64) tiles.push_back({i, q0});
+        }
+        const AttnSeq* d_seqs = c.up(seqs);
+        const AttnTile* d_tiles = c.up(tiles);
+        for (int l = 0; l < cfg.layers; ++l) {
+            const DecLayerW& L = m->dec[l];
+            launch_rmsnorm(hid, L.in_norm, xn, R, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
+            {
+                GemmParams p = gp(c, xn, H, L.qkv, R);
+                p.out = qkv; p.ldo = QKV;
+                launch_gemm(p, A_PLAIN, OUT_BF16, wf, -1, c.s);
+            }
+            RopeParams rp{qkv, QKV, R, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
+                          m->rope_max_pos, d_row_utt, d_row_pos, st_len, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
+            launch_rope(rp, c.s);
+            FlashParams fp{qkv, QKV, kc + l * layer_stride, vc + l * layer_stride, hd, head_stride, att, (int64_t)nh * hd, d_seqs, d_tiles,
+                           (int)tiles.size(), nh, nh / nkv, scale, 1};
+            launch_flash_attn(fp, hd, c.s);
+            {
+                GemmParams p = gp(c, att, (int64_t)nh * hd, L.o, R);
+                p.out = hid; p.ldo = H;
+                launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
+            }
+            launch_rmsnorm(hid, L.post_norm, xn, R, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
+            {
+                GemmParams p = gp(c, xn, H, L.gate_up, R);
+                p.out = act; p.ldo = cfg.inter;
+                launch_gemm(p, A_PLAIN, OUT_SWIGLU, wf, -1, c.s);
+            }
+            {
+                GemmParams p = gp(c, act, cfg.inter, L.down, R);
+                p.out = hid; p.ldo = H;
+                launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
+            }
+        }
+        launch_rmsnorm(hid, m->final_norm, x_last, b, H, cfg.rms_eps, d_last, nullptr, 0, 0, c.s);  // :386, last position only
+        lm_head(x_last, b, 0);
+        step(0);
+        m->arena.restore(mark);
+    }
+    HIP_CHECK(hipEventRecord(ev.e[3], c.s));
+
+    // ---- greedy decode (Qwen3ASR.swift:567-632) ----
+    {
+        float* hd_ = c.get<float>((size_t)b * H);
+        bf16_t* xn = c.get<bf16_t>((size_t)b * H);
+        bf16_t* qkv = c.get<bf16_t>((size_t)b * QKV);
+        bf16_t* att = c.get<bf16_t>((size_t)b * nh * hd);
+        bf16_t* act = c.get<bf16_t>((size_t)b * cfg.inter);
+        int active = b;
+        HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
+        HIP_CHECK(hipStreamSynchronize(c.s));
+        for (int it = 1; it < max_tokens && active > 0; ++it) {
+            launch_embed_tokens(st_next, b, H, qemb ? nullptr : (const bf16_t*)m->embed.w, qemb ? (const uint32_t*)m->embed.w : nullptr,
+                                m->embed.scales, m->embed.biases, cfg.group_size, hd_, c.s);
+            for (int l = 0; l < cfg.layers; ++l) {
+                const DecLayerW& L = m->dec[l];
+                launch_rmsnorm(hd_, L.in_norm, xn, b, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
+                {
+                    GemmParams p = gp(c, xn, H, L.qkv, b);
+                    p.out = qkv; p.ldo = QKV;
+                    launch_gemm(p, A_PLAIN, OUT_BF16, wf, -1, c.s);
+                }
+                RopeParams rp{qkv, QKV, b, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
+                              m->rope_max_pos, nullptr, nullptr, st_len, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
+                launch_rope(rp, c.s);
+                DecodeAttnParams dp{qkv, QKV, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride, st_len, 1, att,
+                                    (int64_t)nh * hd, b, nkv, nh / nkv, scale};
+                launch_decode_attn(dp, hd, c.s);
+                {
+                    GemmParams p = gp(c, att, (int64_t)nh * hd, L.o, b);
+                    p.out = hd_; p.ldo = H;
+                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
+                }
+                launch_rmsnorm(hd_, L.post_norm, xn, b, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
+                {
+                    GemmParams p = gp(c, xn, H, L.gate_up, b);
+                    p.out = act; p.ldo = cfg.inter;
+                    launch_gemm(p, A_PLAIN, OUT_SWIGLU, wf, -1, c.s);
+                }
+                {
+                    GemmParams p = gp(c, act, cfg.inter, L.down, b);
+                    p.out = hd_; p.ldo = H;
+                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
+                }
+            }
+            launch_rmsnorm(hd_, m->final_norm, x_last, b, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
+            lm_head(x_last, b, it);
+            step(1);
+            res->decode_steps += 1;
+            if (it % POLL_STEPS == 0 || it + 1 == max_tokens) {
+                HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
+                HIP_CHECK(hipStreamSynchronize(c.s));
+            }
+        }
+    }
+    HIP_CHECK(hipEventRecord(ev.e[4], c.s));
+
+    // ---- results ----
+    std::vector<int> h_tokens((size_t)b * max_tokens), h_ntok(b);
+    HIP_CHECK(hipMemcpyAsync(h_tokens.data(), st_tokens, h_tokens.size() * 4, hipMemcpyDeviceToHost, c.s));
+    HIP_CHECK(hipMemcpyAsync(h_ntok.data(), st_ntok, (size_t)b * 4, hipMemcpyDeviceToHost, c.s));
+    HIP_CHECK(hipStreamSynchronize(c.s));
+    for (int i = 0; i < b; ++i) {
+        // tokens appended after an utterance stopped are not part of its transcript
+        res->n_tokens[idx[i]] = h_ntok[i];
+        memcpy(res->tokens + (size_t)idx[i] * max_tokens, &h_tokens[(size_t)i * max_tokens], (size_t)h_ntok[i] * 4);
+        res->tokens_total += h_ntok[i];
+    }
+    float ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev.e[0], ev.e[1])); res->ms_mel += ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev.e[1], ev.e[2])); res->ms_encoder += ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev.e[2], ev.e[3])); res->ms_prefill += ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev.e[3], ev.e[4])); res->ms_decode += ms;
+    c.keep.clear();
+}
+
+}  // namespace
+
+void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* res) {
+    Q3_REQUIRE(m->finalized, "transcribe: weights not finalized");
+    Q3_REQUIRE(req && res && req->audio && req->offsets && res->tokens && res->n_tokens, "transcribe: null argument");
+    Q3_REQUIRE(req->n_utt > 0, "transcribe: empty batch");
+    Q3_REQUIRE(req->max_tokens >= 1 && req->max_tokens <= 2048, "transcribe: max_tokens must be in [1, 2048]");
+    Q3_REQUIRE(req->sample_rate > 0, "transcribe: sample rate must be positive");
+    HIP_CHECK(hipSetDevice(m->device));
+    const q3asr_config& cfg = m->cfg;
+    const int n = req->n_utt;
+    res->audio_seconds = res->ms_mel = res->ms_encoder = res->ms_prefill = res->ms_decode = 0;
+    res->decode_steps = res->tokens_total = 0;
+    // per-utterance sizes in request order (tap layouts) and the length-sorted processing order
+    std::vector<int> frames(n), order(n);
+    std::vector<int64_t> tap_a_off(n + 1, 0), tap_s_off(n + 1, 0);
+    const double ratio = 16000.0 / (double)req->sample_rate;
+    for (int u = 0; u < n; ++u) {
+        const int64_t len = req->offsets[u + 1] - req->offsets[u];
+        Q3_REQUIRE(len >= 0, "transcribe: offsets must be non-decreasing");
+        const int64_t n16 = req->sample_rate == 16000 ? len : (int64_t)((double)len * ratio);
+        Q3_REQUIRE(n16 >= MEL_HOP, "transcribe: an utterance is shorter than one 10 ms frame");
+        frames[u] = mel_frames_out(n16);
+        const int na = model_output_length(cfg, frames[u]);
+        int nl = 0;
+        if (req->lang_ids && req->lang_offsets) {
+            nl = req->lang_offsets[u + 1] - req->lang_offsets[u];
+            bool has = false;
+            for (int k = req->lang_offsets[u]; k < req->lang_offsets[u + 1]; ++k) has |= req->lang_ids[k] == TOK_ASR_TEXT;
+            if (nl > 0 && !has) nl += 1;
+        }
+        tap_a_off[u + 1] = tap_a_off[u] + na;
+        tap_s_off[u + 1] = tap_s_off[u] + na + 15 + nl;
+    }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return frames[a] > frames[b]; });
+    const int mb = std::max(1, cfg.max_batch);
+    for (int g0 = 0; g0 < n; g0 += mb) {
+        std::vector<int> idx(order.begin() + g0, order.begin() + std::min(n, g0 + mb));
+        m->arena.reset();
+        Ctx c{m, m->stream, {}};
+        transcribe_group(c, req, res, idx, tap_a_off, tap_s_off);
+    }
+}

@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's model API over the C ABI.
+
+Names and argument meaning follow the reference: ``Qwen3ASRModel.from_pretrained``
+/ ``transcribe(audio, sample_rate, language, max_tokens)`` (Qwen3ASR.swift:60-145,
+693-770), ``WhisperFeatureExtractor.process`` (AudioPreprocessing.swift:330-344)
+and ``Qwen3AudioEncoder.__call__`` (AudioEncoder.swift:325-501).  The batched
+entry points (``transcribe_batch``) are what the reference lacks: it is batch-1.
+All arithmetic happens in libq3asr.so on the GPU; nothing here computes.
+"""
+import ctypes
+import json
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import lib as _lib
+from .config import Q3Config, make_config
+
+_TAG2DT = {"f32": _lib.F32, "bf16": _lib.BF16, "u32": _lib.U32}
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+@dataclass
+class TranscribeOutput:
+    tokens: list                       # per utterance: list[int] (generated ids, EOS included when emitted)
+    n_audio_tokens: np.ndarray
+    audio_seconds: float
+    ms: dict                           # device time per stage
+    decode_steps: int
+    tokens_total: int
+    taps: dict = field(default_factory=dict)
+
+
+class WhisperFeatureExtractor:
+    """AudioPreprocessing.swift:8-366 (constants :9-13)."""
+    sample_rate, n_fft, hop_length, n_mels, chunk_length = 16000, 400, 160, 128, 30
+
+    def __init__(self, model):
+        self._m = model
+
+    def mel_filterbank(self):
+        out = np.empty((128, 201), dtype=np.float32)
+        _lib.check(self._m._lib, self._m._lib.q3asr_mel_filterbank(self._m._h, out.ctypes.data))
+        return out
+
+    def process(self, audio, sample_rate):
+        """One utterance -> [128, T] fp32 log-mel."""
+        return self.process_batch([audio], sample_rate)[0]
+
+    def process_batch(self, audios, sample_rate, t_stride=3000):
+        m = self._m
+        audios = [np.ascontiguousarray(a, dtype=np.float32) for a in audios]
+        off = np.zeros(len(audios) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(a) for a in audios])
+        cat = np.concatenate(audios) if audios else np.zeros(0, np.float32)
+        if cat.size == 0:
+            cat = np.zeros(1, np.float32)
+        out = np.empty((len(audios), 128, t_stride), dtype=np.float32)
+        nfr = np.zeros(len(audios), dtype=np.int32)
+        _lib.check(m._lib, m._lib.q3asr_mel(m._h, cat.ctypes.data, _ptr(off, ctypes.c_int64), len(audios), int(sample_rate),
+                                            _lib.HOST, out.ctypes.data, t_stride, _ptr(nfr, ctypes.c_int32), _lib.HOST))
+        return [np.ascontiguousarray(out[i, :, :nfr[i]]) for i in range(len(audios))]
+
+
+class Qwen3AudioEncoder:
+    """AudioEncoder.swift:173-502."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def output_length(self, n_frames):
+        return int(self._m._lib.q3asr_output_length(self._m._h, int(n_frames)))
+
+    def __call__(self, mel):
+        """mel [128, T] fp32 (or [1, 128, T]) -> [N, out_dim] fp32."""
+        mel = np.asarray(mel, dtype=np.float32)
+        if mel.ndim == 3:
+            mel = mel[0]                       # AudioEncoder.swift:356 reads batch item 0 only
+        return self.encode_batch([mel])[0]
+
+    def encode_batch(self, mels):
+        m = self._m
+        t_stride = max(4, max(x.shape[1] for x in mels))
+        buf = np.zeros((len(mels), 128, t_stride), dtype=np.float32)
+        nfr = np.zeros(len(mels), dtype=np.int32)
+        for i, x in enumerate(mels):
+            buf[i, :, :x.shape[1]] = x
+            nfr[i] = x.shape[1]
+        cap = int(sum(self.output_length(int(n)) for n in nfr))
+        out = np.empty((max(cap, 1), m.cfg.enc_out_dim), dtype=np.float32)
+        cu = np.zeros(len(mels) + 1, dtype=np.int32)
+        _lib.check(m._lib, m._lib.q3asr_encode(m._h, buf.ctypes.data, t_stride, _ptr(nfr, ctypes.c_int32), len(mels), _lib.HOST,
+                                               out.ctypes.data, cap, _ptr(cu, ctypes.c_int32), _lib.HOST))
+        return [out[cu[i]:cu[i + 1]].copy() for i in range(len(mels))]
+
+
+class Qwen3ASRModel:
+    def __init__(self, cfg: Q3Config, device=0):
+        self._lib = _lib.load()
+        self.cfg = cfg
+        self.device = device
+        h = ctypes.c_void_p()
+        _lib.check(self._lib, self._lib.q3asr_create(ctypes.byref(cfg), int(device), ctypes.byref(h)))
+        self._h = h
+        self.feature_extractor = WhisperFeatureExtractor(self)
+        self.audio_encoder = Qwen3AudioEncoder(self)
+        self.tokenizer = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.q3asr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights (WeightLoading.swift) ----
+    def load_tensor(self, name, arr, tag):
+        arr = np.ascontiguousarray(arr)
+        shape = (ctypes.c_int64 * arr.ndim)(*arr.shape)
+        _lib.check(self._lib, self._lib.q3asr_load_tensor(self._h, name.encode(), _TAG2DT[tag], shape, arr.ndim, arr.ctypes.data))
+
+    def load_checkpoint(self, ck):
+        for name, (arr, tag) in ck.items():
+            self.load_tensor(name, arr, tag)
+        _lib.check(self._lib, self._lib.q3asr_finalize(self._h))
+
+    @classmethod
+    def from_checkpoint(cls, cfg, ck, device=0):
+        m = cls(cfg, device)
+        m.load_checkpoint(ck)
+        return m
+
+    @classmethod
+    def from_pretrained(cls, model_dir, device=0, **overrides):
+        """Local-directory form of Qwen3ASRModel.fromPretrained (Qwen3ASR.swift:693-770): reads
+        config.json (text_config + quantization, :774-818) and every *.safetensors file."""
+        from .safetensors_io import load_dir
+        with open(os.path.join(model_dir, "config.json")) as f:
+            cj = json.load(f)
+        tc = cj.get("thinker_config", cj).get("text_config", {})
+        quant = cj.get("quantization") or cj.get("quantization_config")
+        preset = "1.7b" if tc.get("hidden_size", 1024) >= 2048 else "0.6b"
+        kw = dict(weight_format=1 if quant else 0)
+        for src, dst in (("hidden_size", "hidden"), ("num_hidden_layers", "layers"), ("num_attention_heads", "heads"),
+                         ("num_key_value_heads", "kv_heads"), ("head_dim", "head_dim"), ("intermediate_size", "inter"),
+                         ("vocab_size", "vocab"), ("rms_norm_eps", "rms_eps"), ("rope_theta", "rope_theta")):
+            if src in tc:
+                kw[dst] = tc[src]
+        kw.update(overrides)
+        m = cls(make_config(preset, **kw), device)
+        m.load_checkpoint(load_dir(model_dir))
+        return m
+
+    # ---- transcription ----
+    def transcribe(self, audio, sample_rate=24000, language=None, max_tokens=448):
+        """Qwen3ASRModel.transcribe (Qwen3ASR.swift:60-145).  Without a tokenizer the reference
+        returns the generated ids joined by spaces (:647-650); so does this."""
+        lang_ids = None
+        if language is not None:
+            if self.tokenizer is None:
+                raise ValueError("forcing a language needs a tokenizer to encode ' language X<asr_text>'")
+            lang_ids = [self.tokenizer.encode(f" language {language}<asr_text>")]
+        out = self.transcribe_batch([audio], sample_rate, max_tokens=max_tokens, lang_ids=lang_ids)
+        toks = out.tokens[0]
+        if self.tokenizer is not None:
+            return self.tokenizer.post_process(self.tokenizer.decode(toks))
+        return " ".join(str(t) for t in toks)
+
+    def transcribe_batch(self, audios, sample_rate=16000, max_tokens=448, lang_ids=None, stop_rules=True, forced_tokens=None,
+                         tap_steps=0, tap_embeds=False, device_audio=None):
+        """audios: list of fp32 arrays (host).  device_audio: (device pointer, offsets int64[n+1]) of samples
+        already resident in HBM, used instead of `audios`."""
+        if device_audio is not None:
+            ptr, off = device_audio
+            off = np.ascontiguousarray(off, dtype=np.int64)
+            n, space = len(off) - 1, _lib.DEVICE
+            keep = None
+        else:
+            audios = [np.ascontiguousarray(a, dtype=np.float32) for a in audios]
+            n = len(audios)
+            off = np.zeros(n + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(a) for a in audios])
+            keep = np.concatenate(audios) if n else np.zeros(1, np.float32)
+            ptr, space = keep.ctypes.data, _lib.HOST
+        req = _lib.Q3Request()
+        req.audio, req.offsets, req.n_utt = ptr, _ptr(off, ctypes.c_int64), n
+        req.sample_rate, req.audio_space = int(sample_rate), space
+        req.max_tokens, req.stop_rules = int(max_tokens), 1 if stop_rules else 0
+        holders = [off, keep]
+        if lang_ids is not None:
+            lo = np.zeros(n + 1, dtype=np.int32)
+            lo[1:] = np.cumsum([len(x) if x is not None else 0 for x in lang_ids])
+            li = np.asarray([t for x in lang_ids if x is not None for t in x] or [0], dtype=np.int32)
+            req.lang_ids, req.lang_offsets = _ptr(li, ctypes.c_int32), _ptr(lo, ctypes.c_int32)
+            holders += [lo, li]
+        if forced_tokens is not None:
+            ft = np.ascontiguousarray(forced_tokens, dtype=np.int32).reshape(n, max_tokens)
+            req.forced_tokens = _ptr(ft, ctypes.c_int32)
+            holders.append(ft)
+        taps = {}
+        if tap_steps:
+            taps["logits"] = np.zeros((n, tap_steps, self.cfg.vocab), dtype=np.float32)
+            req.tap_logits, req.tap_steps = _ptr(taps["logits"], ctypes.c_float), int(tap_steps)
+        if tap_embeds:
+            cap = n * (390 + 64)
+            taps["audio_embeds"] = np.zeros((cap, self.cfg.hidden), dtype=np.float32)
+            taps["inputs_embeds"] = np.zeros((cap, self.cfg.hidden), dtype=np.float32)
+            req.tap_audio_embeds = _ptr(taps["audio_embeds"], ctypes.c_float)
+            req.tap_inputs_embeds = _ptr(taps["inputs_embeds"], ctypes.c_float)
+        tokens = np.zeros((n, max_tokens), dtype=np.int32)
+        ntok = np.zeros(n, dtype=np.int32)
+        naud = np.zeros(n, dtype=np.int32)
+        res = _lib.Q3Result()
+        res.tokens, res.n_tokens, res.n_audio_tokens = _ptr(tokens, ctypes.c_int32), _ptr(ntok, ctypes.c_int32), _ptr(naud, ctypes.c_int32)
+        _lib.check(self._lib, self._lib.q3asr_transcribe_tokens(self._h, ctypes.byref(req), ctypes.byref(res)))
+        del holders
+        return TranscribeOutput(
+            tokens=[tokens[i, :ntok[i]].tolist() for i in range(n)], n_audio_tokens=naud, audio_seconds=res.audio_seconds,
+            ms=dict(mel=res.ms_mel, encoder=res.ms_encoder, prefill=res.ms_prefill, decode=res.ms_decode),
+            decode_steps=int(res.decode_steps), tokens_total=int(res.tokens_total), taps=taps)
+
+    # ---- kernel-level entry points (parity tests) ----
+    def op_gemm(self, a_bits, w_bits, bias=None, gelu=False, tile=-1, ksplit=1):
+        a_bits, w_bits = np.ascontiguousarray(a_bits, np.uint16), np.ascontiguousarray(w_bits, np.uint16)
+        (M, K), N = a_bits.shape, w_bits.shape[0]
+        out = np.empty((M, N), dtype=np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        _lib.check(self._lib, self._lib.q3asr_op_gemm(self._h, a_bits.ctypes.data, w_bits.ctypes.data, None if b is None else b.ctypes.data,
+                                                      M, N, K, int(gelu), tile, ksplit, out.ctypes.data))
+        return out
+
+    def op_gemm_q4(self, a_bits, wq, scales_bits, biases_bits, tile=-1):
+        a_bits = np.ascontiguousarray(a_bits, np.uint16)
+        wq = np.ascontiguousarray(wq, np.uint32)
+        s, b = np.ascontiguousarray(scales_bits, np.uint16), np.ascontiguousarray(biases_bits, np.uint16)
+        (M, K), N = a_bits.shape, wq.shape[0]
+        out = np.empty((M, N), dtype=np.float32)
+        _lib.check(self._lib, self._lib.q3asr_op_gemm_q4(self._h, a_bits.ctypes.data, wq.ctypes.data, s.ctypes.data, b.ctypes.data,
+                                                         M, N, K, tile, out.ctypes.data))
+        return out
+
+    def op_attention(self, q_bits, k_bits, v_bits, cu_seqlens, heads, group, head_dim, causal):
+        q, k, v = (np.ascontiguousarray(x, np.uint16) for x in (q_bits, k_bits, v_bits))
+        cu = np.ascontiguousarray(cu_seqlens, np.int32)
+        out = np.empty_like(q)
+        _lib.check(self._lib, self._lib.q3asr_op_attention(self._h, q.ctypes.data, k.ctypes.data, v.ctypes.data,
+                                                           _ptr(cu, ctypes.c_int32), len(cu) - 1, heads, group, head_dim,
+                                                           int(causal), out.ctypes.data))
+        return out

@@ -1,0 +1,61 @@
+"""GPU parity of the log-mel frontend against the CPU restatement.
+
+Tolerance: 1e-4 absolute against the restatement evaluated with exact twiddles and float64
+accumulation (the value the reference's formula defines); 2.5e-4 against the same restatement
+accumulated in fp32, whose own rounding noise is up to 8e-5 on white noise (two fp32 evaluations
+with different summation orders can therefore differ by more than 1e-4 near the max-8 floor)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, read_wav_pcm16
+from q3asr import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+TOL_F32 = 2.5e-4
+
+
+def _check(got, audio, rate):
+    a16 = audio if rate == 16000 else oracle.mel.resample_linear(audio, rate, 16000)
+    ref64 = oracle.mel.extract_features(a16, "exact", np.float64)
+    ref32 = oracle.mel.extract_features(a16, "exact", np.float32)
+    assert got.shape == ref64.shape
+    assert np.abs(got - ref64).max() <= TOL
+    assert np.abs(got - ref32).max() <= TOL_F32
+    return ref64
+
+
+def test_filterbank_bit_close(tiny_model):
+    fb = tiny_model[0].feature_extractor.mel_filterbank()
+    ref = oracle.mel.mel_filterbank()
+    assert fb.shape == (128, 201)
+    assert np.abs(fb - ref).max() <= 4e-7      # libm logf/expf vs numpy fp32, values up to 0.025
+
+
+@pytest.mark.parametrize("kind", ["speechlike", "noise"])
+def test_mel_synthetic_30s(tiny_model, kind):
+    audio = synth.synth_audio(480000, 11, kind)
+    got = tiny_model[0].feature_extractor.process(audio, 16000)
+    assert _check(got, audio, 16000).shape == (128, 3000)
+
+
+def test_mel_ragged_batch_and_edges(tiny_model):
+    """Ragged lengths, a clip longer than 30 s (truncated to 3000 frames, max taken over the whole
+    clip), clips shorter than one FFT window (reflect padding clamps)."""
+    lens = [160, 333, 1000, 16000, 48017, 160 * 3000 + 5, 16000 * 33 + 77]
+    audios = [synth.synth_audio(n, 100 + i) for i, n in enumerate(lens)]
+    got = tiny_model[0].feature_extractor.process_batch(audios, 16000)
+    for a, g in zip(audios, got):
+        _check(g, a, 16000)
+        assert g.shape[1] == min(len(a) // 160, 3000)
+
+
+def test_mel_test_wav_24k_resample(tiny_model):
+    """The reference's own test clip (24 kHz, 20 s) through the linear resampler (AudioPreprocessing.swift:347-365)."""
+    audio, rate = read_wav_pcm16(os.path.join(GOLDEN, "test_audio.wav"))
+    assert rate == 24000 and len(audio) == 480000
+    got = tiny_model[0].feature_extractor.process(audio, rate)
+    assert _check(got, audio, rate).shape == (128, 2000)

@@ -1,0 +1,115 @@
+"""GPU parity of the encoder, prompt splice, prefill and greedy decode against the CPU restatement."""
+import numpy as np
+import pytest
+
+import oracle
+from q3asr import Qwen3ASRModel, make_config, oracle_cfgs, synth
+
+pytestmark = pytest.mark.gpu
+
+# bf16 activations between GEMMs on the GPU vs fp32 in the restatement
+ENC_RTOL = 3e-2
+LOGIT_RTOL = 4e-2
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-9)
+
+
+@pytest.mark.parametrize("frames", [250, 100, 37, 3000, 1234])
+def test_encoder_matches_oracle(tiny_model, frames):
+    m, cfg, ck = tiny_model
+    w = synth.checkpoint_to_f32(ck)
+    enc_cfg, _ = oracle_cfgs(cfg)
+    mel = oracle.mel.process(synth.synth_audio(frames * 160, frames), 16000)
+    assert mel.shape[1] == frames
+    got = m.audio_encoder(mel)
+    ref = oracle.encoder.encode(mel, w, enc_cfg)
+    assert got.shape == ref.shape == (oracle.encoder.output_length(frames), cfg.enc_out_dim)
+    assert _rel(got, ref) <= ENC_RTOL
+
+
+def test_encoder_batch_equals_single(tiny_model):
+    m, cfg, _ = tiny_model
+    mels = [oracle.mel.process(synth.synth_audio(n * 160, n), 16000) for n in (250, 1000, 99, 100)]
+    batch = m.audio_encoder.encode_batch(mels)
+    for x, b in zip(mels, batch):
+        assert np.array_equal(m.audio_encoder(x), b)
+
+
+def _oracle_run(cfg, ck, audio, max_tokens, embed_scale=True):
+    w = synth.checkpoint_to_f32(ck)
+    enc_cfg, dec_cfg = oracle_cfgs(cfg)
+    trace, stages = [], {}
+    toks = oracle.generate.transcribe_tokens(audio, 16000, w, enc_cfg, dec_cfg, max_tokens=max_tokens, trace=trace,
+                                             stages=stages, embed_scale=embed_scale)
+    return toks, np.stack(trace), stages
+
+
+@pytest.mark.parametrize("variant", ["default", "rotate_half", "no_embed_scale", "q4"])
+def test_transcribe_teacher_forced_logits(variant):
+    """Per-step logits under teacher forcing with the oracle's own tokens, every decode path
+    (interleaved / rotate-half RoPE, embed rescale on / off, dense / MLX-q4 weights)."""
+    kw = dict(rotate_half=dict(rope_interleaved=0), no_embed_scale=dict(embed_scale=0), q4=dict(weight_format=1)).get(variant, {})
+    cfg = make_config("tiny", **kw)
+    ck = synth.make_checkpoint(cfg, seed=3)
+    audio = synth.synth_audio(16000 * 2 + 4000, 21)
+    steps = 10
+    toks, ref_logits, stages = _oracle_run(cfg, ck, audio, steps, embed_scale=bool(cfg.embed_scale))
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        forced = np.zeros((1, steps), dtype=np.int32)
+        forced[0, :len(toks)] = toks
+        out = m.transcribe_batch([audio], 16000, max_tokens=steps, forced_tokens=forced, tap_steps=steps, tap_embeds=True)
+        n_a = int(out.n_audio_tokens[0])
+        assert n_a == stages["audio_embeds"].shape[0]
+        assert _rel(out.taps["audio_embeds"][:n_a], stages["audio_embeds"]) <= ENC_RTOL
+        s = stages["inputs_embeds"].shape[0]
+        assert _rel(out.taps["inputs_embeds"][:s], stages["inputs_embeds"]) <= ENC_RTOL
+        got = out.taps["logits"][0, :len(toks)]
+        assert _rel(got, ref_logits[:len(toks)]) <= LOGIT_RTOL
+        # tokens agree wherever the oracle's top-2 margin exceeds the logit tolerance
+        for i in range(len(toks)):
+            srt = np.sort(ref_logits[i])
+            margin = srt[-1] - srt[-2]
+            if margin > 2 * LOGIT_RTOL * np.abs(ref_logits[i]).max():
+                assert out.tokens[0][i] == toks[i]
+    finally:
+        m.close()
+
+
+def test_fused_argmax_equals_logit_tap(tiny_model):
+    """The LM-head + argmax epilogue must pick the same ids as argmax over the tapped fp32 logits."""
+    m, cfg, _ = tiny_model
+    audios = [synth.synth_audio(n, 50 + i) for i, n in enumerate((16000, 40000, 52345))]
+    a = m.transcribe_batch(audios, 16000, max_tokens=12, stop_rules=False)
+    b = m.transcribe_batch(audios, 16000, max_tokens=12, stop_rules=False, tap_steps=12)
+    assert a.tokens == b.tokens
+    for i in range(len(audios)):
+        assert np.array_equal(np.argmax(b.taps["logits"][i], axis=-1), np.array(b.tokens[i]))
+
+
+def test_batch_equals_single_and_order(tiny_model):
+    """Utterances are sorted by length internally; results come back in request order and do not
+    depend on what else is in the batch."""
+    m, cfg, _ = tiny_model
+    audios = [synth.synth_audio(n, 70 + i) for i, n in enumerate((20000, 100000, 16000, 64000))]
+    batch = m.transcribe_batch(audios, 16000, max_tokens=8, stop_rules=False)
+    for i, a in enumerate(audios):
+        single = m.transcribe_batch([a], 16000, max_tokens=8, stop_rules=False)
+        assert single.tokens[0] == batch.tokens[i]
+    assert abs(batch.audio_seconds - sum(len(a) for a in audios) / 16000.0) < 1e-6
+
+
+def test_greedy_free_running_matches_oracle_prefix(tiny_model):
+    """Free-running greedy decode: identical ids up to the first step whose oracle margin is within tolerance."""
+    m, cfg, ck = tiny_model
+    audio = synth.synth_audio(30000, 99)
+    toks, ref_logits, _ = _oracle_run(cfg, ck, audio, 16)
+    out = m.transcribe_batch([audio], 16000, max_tokens=16)
+    got = out.tokens[0]
+    for i in range(min(len(toks), len(got))):
+        srt = np.sort(ref_logits[i])
+        if srt[-1] - srt[-2] <= 2 * LOGIT_RTOL * np.abs(ref_logits[i]).max():
+            break
+        assert got[i] == toks[i]

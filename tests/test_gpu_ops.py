@@ -1,0 +1,92 @@
+"""GPU parity of the kernel-level entry points (GEMM variants, attention) through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import bf16_bits, bf16_vals
+
+pytestmark = pytest.mark.gpu
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("M,N,K,tile,ksplit,gelu,bias", [
+    (128, 128, 64, 0, 1, False, False),
+    (300, 480, 4320, 0, 1, True, True),      # conv-shaped: N, K not multiples of the tile, K tail of 32
+    (405, 2048, 1024, 0, 1, False, True),
+    (7, 896, 896, 1, 1, False, True),        # ragged M on the 64x64 tile
+    (130, 192, 96, 1, 1, True, False),
+    (64, 1024, 3072, 1, 4, False, False),    # split-K slabs
+    (200, 320, 512, 2, 1, False, True),      # 128x64 tile
+    (1, 151936, 256, 0, 1, False, False),    # LM-head shape, one row
+])
+def test_gemm_matches_fp64(tiny_model, M, N, K, tile, ksplit, gelu, bias):
+    m = tiny_model[0]
+    rng = np.random.default_rng(M * 7 + N)
+    a = bf16_bits(rng.standard_normal((M, K)) * 0.5)
+    w = bf16_bits(rng.standard_normal((N, K)) / np.sqrt(K))
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32) if bias else None
+    out = m.op_gemm(a, w, b, gelu, tile, ksplit)
+    ref = bf16_vals(a).astype(np.float64) @ bf16_vals(w).astype(np.float64).T
+    if bias:
+        ref = ref + b
+    if gelu:
+        ref = _gelu(ref)
+    tol = 2e-5 * np.sqrt(K) + 1e-6       # fp32 accumulation of exact bf16 products
+    assert np.abs(out - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(2, 256, 128, 1), (1, 2048, 1024, 1), (1, 3072, 1024, 1), (96, 512, 1024, 0)])
+def test_gemm_q4_matches_dequant_reference(tiny_model, M, N, K, tile):
+    """Fused quantised GEMM vs dequantise + matmul on the shapes of Diagnostics.swift:50-105."""
+    import oracle
+    m = tiny_model[0]
+    rng = np.random.default_rng(N + K)
+    wq, s, b = oracle.q4.quantize(rng.standard_normal((N, K)).astype(np.float32) * 0.05)
+    a = bf16_bits(rng.standard_normal((M, K)) * 0.5)
+    out = m.op_gemm_q4(a, wq, bf16_bits(s), bf16_bits(b), tile)
+    wd = oracle.q4.dequantize(wq, s, b, 64, round_bf16=True).astype(np.float64)   # the kernel feeds bf16 to the MFMA
+    ref = bf16_vals(a).astype(np.float64) @ wd.T
+    assert np.abs(out - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+    exact = bf16_vals(a).astype(np.float64) @ oracle.q4.dequantize(wq, s, b, 64).astype(np.float64).T
+    assert np.abs(out - exact).max() <= 2e-2 * max(1.0, np.abs(exact).max())       # bf16 rounding of q*s+b
+
+
+def _ref_attention(q, k, v, cu, heads, group, hd, causal):
+    rows = q.shape[0]
+    kvh = heads // group
+    q = q.reshape(rows, heads, hd).astype(np.float64)
+    k = k.reshape(rows, kvh, hd).astype(np.float64)
+    v = v.reshape(rows, kvh, hd).astype(np.float64)
+    out = np.zeros((rows, heads, hd))
+    for a, b in zip(cu[:-1], cu[1:]):
+        for h in range(heads):
+            s = q[a:b, h] @ k[a:b, h // group].T / np.sqrt(hd)
+            if causal:
+                s = s + np.triu(np.ones_like(s), 1) * -1e9
+            s = s - s.max(axis=1, keepdims=True)
+            p = np.exp(s)
+            p /= p.sum(axis=1, keepdims=True)
+            out[a:b, h] = p @ v[a:b, h // group]
+    return out.reshape(rows, heads * hd)
+
+
+@pytest.mark.parametrize("lens,heads,group,hd,causal", [
+    ([104, 104, 104, 78], 14, 1, 64, False),     # encoder windows of a 30 s clip
+    ([13, 7, 1], 2, 1, 64, False),
+    ([405, 275], 16, 2, 128, True),              # decoder prompts, GQA
+    ([33, 65, 64], 4, 2, 128, True),
+])
+def test_attention_matches_fp64(tiny_model, lens, heads, group, hd, causal):
+    m = tiny_model[0]
+    rng = np.random.default_rng(sum(lens) + heads)
+    rows = sum(lens)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    q = bf16_bits(rng.standard_normal((rows, heads * hd)))
+    k = bf16_bits(rng.standard_normal((rows, heads // group * hd)))
+    v = bf16_bits(rng.standard_normal((rows, heads // group * hd)))
+    out = bf16_vals(m.op_attention(q, k, v, cu, heads, group, hd, causal))
+    ref = _ref_attention(bf16_vals(q), bf16_vals(k), bf16_vals(v), cu, heads, group, hd, causal)
+    assert np.abs(out - ref).max() <= 2e-2     # P and O are rounded to bf16
