@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""RTFx benchmark of the Qwen3-ASR offline-transcription hot path on MI355X.
+
+One "step" = one pass of the whole hot path (log-mel -> audio encoder -> prompt splice -> decoder
+prefill -> greedy KV-cache decode with the reference's stop rules) over a batch of synthetic 30 s
+clips that already sit in HBM.  Metric: RTFx = audio seconds transcribed / wall seconds, summed
+over all ranks (weak scaling: every GPU gets its own --batch clips, utterance-sharded, no data-path
+collective).  Weights are seeded random tensors of the true Qwen3-ASR-1.7B shapes (no checkpoint
+exists offline); with such weights the decoder never emits EOS, so every clip runs the reference's
+full max_tokens = 448 greedy steps -- the most expensive case the reference's loop allows.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "qwen3-asr-swift_amd"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def cpu_baseline(cfg, ck, audio, decode_steps):
+    """CPU restatement of the reference algorithm (numpy fp32; NOT the reference's Swift/MLX build,
+    which cannot be produced here), timed on this box's host cores on one clip of the same workload.
+    Decode is timed for `decode_steps` greedy steps and extrapolated to the 448 the GPU run executes."""
+    import oracle
+    from q3asr import oracle_cfgs, synth
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(threads, int(os.environ.get("OMP_NUM_THREADS", threads)))
+    w = synth.checkpoint_to_f32(ck)
+    enc_cfg, dec_cfg = oracle_cfgs(cfg)
+    t0 = time.perf_counter()
+    feats = oracle.mel.process(audio, 16000)
+    t1 = time.perf_counter()
+    a = oracle.encoder.encode(feats, w, enc_cfg)
+    t2 = time.perf_counter()
+    dec = oracle.decoder.Decoder(w, dec_cfg)
+    ids, a0, a1 = oracle.generate.prompt_ids(a.shape[0])
+    x = oracle.generate.splice(dec, ids, a0, a1, a, bool(cfg.embed_scale))
+    t3 = time.perf_counter()
+    h, cache = dec.forward(x, None)
+    nxt = int(np.argmax(dec.logits(h[-1:])[0]))
+    t4 = time.perf_counter()
+    for _ in range(decode_steps):
+        h, cache = dec.forward(dec.embed([nxt]), cache)
+        nxt = int(np.argmax(dec.logits(h)[0]))
+    t5 = time.perf_counter()
+    per_step = (t5 - t4) / max(decode_steps, 1)
+    total = (t1 - t0) + (t2 - t1) + (t4 - t3) + per_step * 447
+    return {
+        "value": round(len(audio) / 16000.0 / total, 4), "unit": "RTFx (audio s per wall s)", "cores": threads, "kind": "port",
+        "sample": f"1 clip x 30 s, 1.7B dims, numpy fp32 restatement: mel {t1 - t0:.2f} s + encoder {t2 - t1:.2f} s + prefill "
+                  f"{t4 - t3:.2f} s measured; decode {per_step * 1e3:.1f} ms/step measured over {decode_steps} steps and "
+                  f"extrapolated to 447 steps",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--preset", default="1.7b")
+    ap.add_argument("--batch", type=int, default=128, help="30 s clips per GPU per step")
+    ap.add_argument("--clip-seconds", type=float, default=30.0)
+    ap.add_argument("--max-tokens", type=int, default=448)
+    ap.add_argument("--no-stop-rules", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-decode-steps", type=int, default=8)
+    ap.add_argument("--profile-stride", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from q3asr import Qwen3ASRModel, make_config, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libq3asr has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = make_config(args.preset, max_batch=args.batch)
+    ck = synth.make_checkpoint(cfg, seed=0)
+    model = Qwen3ASRModel.from_checkpoint(cfg, ck, device=local_rank)
+    n = int(args.clip_seconds * 16000)
+    clips = [synth.synth_audio(n, 1234 + rank * args.batch + i) for i in range(args.batch)]
+    dev_audio = torch.from_numpy(np.concatenate(clips)).cuda()
+    offsets = np.arange(args.batch + 1, dtype=np.int64) * n
+
+    def step():
+        return model.transcribe_batch(None, 16000, max_tokens=args.max_tokens, stop_rules=not args.no_stop_rules,
+                                      device_audio=(dev_audio.data_ptr(), offsets))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.profile_start(args.profile_stride)
+    fence()
+    t0 = time.perf_counter()
+    outs = [step() for _ in range(args.steps)]
+    fence()
+    dt = time.perf_counter() - t0
+    prof = model.profile_stop()
+
+    audio_s = sum(o.audio_seconds for o in outs)
+    tokens = sum(o.tokens_total for o in outs)
+    stats = torch.tensor([dt, audio_s, float(tokens)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+    audio_s, tokens = float(stats[1]), float(stats[2])
+
+    if rank == 0:
+        # dominant kernel by device time (sampled HIP-event timings scaled to all launches)
+        for p in prof:
+            p["ms_est"] = p["ms_timed"] * p["launches"] / max(p["timed"], 1)
+        prof.sort(key=lambda p: -p["ms_est"])
+        top = prof[0]
+        per_launch_work = top["work_timed"] / max(top["timed"], 1)
+        avg_ms = top["ms_timed"] / max(top["timed"], 1)
+        if top["name"].startswith(("gemm", "flash")):
+            ach, peak, unit, bound = per_launch_work / (avg_ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = per_launch_work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+        ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
+        line = {
+            "metric": "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips", "value": round(audio_s / dt, 2),
+            "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen3-ASR-{args.preset} bf16 full transcribe (mel+encoder+prefill+greedy decode, reference stop "
+                                   f"rules, max_tokens {args.max_tokens}), {args.batch} x {args.clip_seconds:g} s synthetic 16 kHz clips "
+                                   f"per GPU per step, audio resident in HBM, seeded random weights of the true shapes",
+                       "clips_per_gpu": args.batch, "tokens_per_clip": round(tokens / (world * args.batch * args.steps), 1),
+                       "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}"},
+            "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                         "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                         "work_per_launch": per_launch_work, "share_of_device_time": round(top["ms_est"] / sum(p["ms_est"] for p in prof), 3)},
+            "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
+                         "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:8]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            model.close()
+            del dev_audio
+            line["cpu_baseline"] = cpu_baseline(cfg, ck, clips[0], args.cpu_decode_steps)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,13 @@ typedef struct q3asr_result {
  * greedy KV-cache loop with the stop rules (:562-632), for a batch of utterances. */
 int q3asr_transcribe_tokens(q3asr_model* m, const q3asr_request* req, q3asr_result* res);
 
+/* Per-kernel timing (no counterpart in the reference, which has no profiling: only wall-clock around
+ * transcribe in Qwen3ASRIntegrationTests.swift:131-136).  Between start and stop every `stride`-th launch
+ * of each kernel is bracketed by HIP events on the model's stream; stop writes a JSON array of
+ * {"name","launches","timed","ms_timed","work","work_timed"} (work = algorithmic FLOPs or bytes). */
+int q3asr_profile_start(q3asr_model* m, int stride);
+int q3asr_profile_stop(q3asr_model* m, char* json_out, int capacity);
+
 /* Kernel-level entry points used by the parity tests (host buffers).
  * q3asr_op_gemm: out[M][N] fp32 = act(A[M][K] * W[N][K]^T + bias), bf16 operands; tile / ksplit select the kernel variant. */
 int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const float* bias, int M, int N, int K, int gelu,

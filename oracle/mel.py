@@ -111,7 +111,7 @@ def n_frames_out(n_samples):
     return min(max(n_frames_total(n_samples) - 1, 0), MAX_FRAMES)
 
 
-def log_mel_raw(audio, mode="exact", accumulate=f32):
+def log_mel_raw(audio, mode="exact", accumulate=f32, fb=None):
     """log10(max(mel, 1e-10)) for ALL frames [nFrames, 128] and the global max
     -- AudioPreprocessing.swift:131-270 (before clamp / scale / trimming)."""
     audio = np.asarray(audio, dtype=f32)
@@ -123,15 +123,18 @@ def log_mel_raw(audio, mode="exact", accumulate=f32):
     re = (frames.astype(accumulate) @ tr.T.astype(accumulate))           # :197-205
     im = (frames.astype(accumulate) @ ti.T.astype(accumulate))
     power = (re * re + im * im).astype(f32)                              # :207
-    fb = mel_filterbank()
+    fb = mel_filterbank() if fb is None else np.asarray(fb, dtype=f32)
     mel = (power.astype(accumulate) @ fb.T.astype(accumulate)).astype(f32)  # :232-240
     logmel = np.log10(np.maximum(mel, f32(1e-10))).astype(f32)           # :252-255
     return logmel, f32(logmel.max()) if logmel.size else f32(0)
 
 
-def extract_features(audio, mode="exact", accumulate=f32):
-    """[128, T] fp32 log-mel -- AudioPreprocessing.swift:131-324."""
-    logmel, mx = log_mel_raw(audio, mode, accumulate)
+def extract_features(audio, mode="exact", accumulate=f32, fb=None):
+    """[128, T] fp32 log-mel -- AudioPreprocessing.swift:131-324.  fb: filterbank override (the
+    [128, 201] table is ill-conditioned in its smallest edge weights: two correct fp32 evaluations of
+    AudioPreprocessing.swift:98-102 with different libm exp/log differ by 2e-7 absolute, which is 0.2 %
+    of the smallest weight)."""
+    logmel, mx = log_mel_raw(audio, mode, accumulate, fb)
     x = np.maximum(logmel, f32(mx - f32(8.0)))                           # :269-276
     x = ((x + f32(4.0)) / f32(4.0)).astype(f32)                          # :286-288
     t = min(max(x.shape[0] - 1, 0), MAX_FRAMES)                          # :301-316

@@ -1,5 +1,6 @@
 // extern "C" surface of libq3asr (declared in include/q3asr.h).
 #include "model.h"
+#include "prof.h"
 #include <cstring>
 
 static thread_local std::string g_last_error;
@@ -124,6 +125,23 @@ int q3asr_transcribe_tokens(q3asr_model* m, const q3asr_request* req, q3asr_resu
     Q3_API_BEGIN
     Q3_REQUIRE(m, "transcribe: null model");
     model_transcribe(m, req, res);
+    Q3_API_END
+}
+
+int q3asr_profile_start(q3asr_model* m, int stride) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m, "profile_start: null model");
+    prof_start(m->stream, stride);
+    Q3_API_END
+}
+
+int q3asr_profile_stop(q3asr_model* m, char* json_out, int capacity) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && json_out && capacity > 2, "profile_stop: null argument");
+    HIP_CHECK(hipSetDevice(m->device));
+    const std::string j = prof_stop();
+    Q3_REQUIRE((int)j.size() + 1 <= capacity, "profile_stop: buffer too small");
+    memcpy(json_out, j.c_str(), j.size() + 1);
     Q3_API_END
 }
 

@@ -23,7 +23,8 @@ struct FlashParams {
     float scale;
     int causal;
 };
-void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s);
+// work: algorithmic FLOPs of the launch (profiling only)
+void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s, double work = 0);
 
 struct DecodeAttnParams {
     const bf16_t* Q; int64_t q_ld;          // Q[u][head*D + d] (already normalised + rotated)
@@ -34,4 +35,5 @@ struct DecodeAttnParams {
     int B, kv_heads, group;
     float scale;
 };
-void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s);
+// work: algorithmic K/V bytes of the launch (profiling only)
+void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, double work = 0);

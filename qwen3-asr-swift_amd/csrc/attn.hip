@@ -13,6 +13,7 @@
 // K/V stream).  HBM-bound: K rows go straight from global memory into MFMA A fragments, the
 // probabilities are exchanged through a few LDS words, V rows are consumed coalesced by the VALU.
 #include "attn.h"
+#include "prof.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -262,11 +263,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
 
 }  // namespace
 
-void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s) {
+void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s, double work) {
     if (p.n_tiles <= 0) return;
     Q3_REQUIRE(head_dim == 64 || head_dim == 128, "flash attention: head_dim must be 64 or 128");
     Q3_REQUIRE(p.q_ld % 8 == 0 && p.kv_ld % 8 == 0 && p.kv_hs % 8 == 0 && p.o_ld % 4 == 0, "flash attention: misaligned strides");
     dim3 grid(p.n_tiles, p.heads), block(256);
+    ProfScope ps(head_dim == 64 ? (p.causal ? "flash_kernel<64,true>" : "flash_kernel<64,false>")
+                                : (p.causal ? "flash_kernel<128,true>" : "flash_kernel<128,false>"), work);
     if (head_dim == 64) {
         if (p.causal) hipLaunchKernelGGL((flash_kernel<64, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_kernel<64, false>), grid, block, 0, s, p);
@@ -277,10 +280,11 @@ void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s) {
+void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, double work) {
     if (p.B <= 0) return;
     Q3_REQUIRE(head_dim == 128, "decode attention: head_dim must be 128");
     dim3 grid(p.B, p.kv_heads), block(256);
+    ProfScope ps("decode_attn_kernel", work);
     switch (p.group) {
         case 1: hipLaunchKernelGGL((decode_attn_kernel<1>), grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL((decode_attn_kernel<2>), grid, block, 0, s, p); break;

@@ -10,6 +10,7 @@
 // MFMA rows through a permutation that makes every lane own 4*NT contiguous columns of a row, so
 // the epilogue stores 16-byte vectors.
 #include "gemm.h"
+#include "prof.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -294,7 +295,12 @@ void launch_t(const GemmParams& p, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<MT, NT, AMODE, OUT, WFMT>), dim3(tiles, 1, p.ksplit), dim3(256), lds, s, p);
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof name, "gemm_kernel<%d,%d,%d,%d,%d>", MT, NT, AMODE, OUT, WFMT);
+    {
+        ProfScope ps(name, 2.0 * p.M * p.N * p.K);
+        hipLaunchKernelGGL((gemm_kernel<MT, NT, AMODE, OUT, WFMT>), dim3(tiles, 1, p.ksplit), dim3(256), lds, s, p);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

@@ -8,7 +8,7 @@ constexpr int MEL_TILE_FRAMES = 64;
 
 struct MelTables {           // device-resident constants, built once per model
     float* hann = nullptr;   // [208]  periodic Hann, zero beyond n = 200
-    float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT
+    float* twid = nullptr;   // [51][2][13][64] MFMA B-fragments of the folded DFT
     int* fb_lo = nullptr;    // [128] first FFT bin of each mel filter
     int* fb_cnt = nullptr;   // [128] number of bins
     int* fb_off = nullptr;   // [128] offset into fb_w
@@ -33,6 +33,6 @@ void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, d
 // d_tile_utt / d_tile_f0: one entry per 64-frame tile.  out: [B][128][t_stride] raw log10 mel.
 // d_max: [B] order-preserving encodings of the per-utterance maximum (zeroed by the caller).
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
-                const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s);
+                const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work = 0);
 // In-place clamp / scale of rows [0, frames_out[u]) with the per-utterance maximum.
 void launch_mel_normalize(float* out, int B, int t_stride, const int* d_frames_out, const unsigned* d_max, hipStream_t s);

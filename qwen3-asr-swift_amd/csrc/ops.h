@@ -30,8 +30,13 @@ void launch_rmsnorm(float* x, const float* w, bf16_t* out, int rows, int d, floa
 
 // Per-head q/k RMSNorm + RoPE + KV-cache append (QuantizedTextDecoder.swift:148-169, 211-268).
 struct RopeParams {
-    bf16_t* qkv;            // [rows][(heads + 2 kv_heads) * 128]; q heads are rewritten in place
+    const bf16_t* qkv;      // [rows][(heads + 2 kv_heads) * 128] projections (ignored when slab != null)
     int64_t ld;
+    const float* slab;      // split-K partial sums [nslab][rows][ld] of the same projections, or null
+    int nslab;
+    int64_t slab_stride;
+    bf16_t* q_out;          // [rows][q_ld]: normalised + rotated queries (may alias qkv)
+    int64_t q_ld;
     int rows, heads, kv_heads;
     const float* q_norm_w;  // [128]
     const float* k_norm_w;
@@ -90,3 +95,7 @@ struct StepParams {
     int B, max_tokens, advance, stop_rules;
 };
 void launch_step(const StepParams& p, hipStream_t s);
+
+// SwiGLU over split-K partial sums of the interleaved gate/up projection (blocks of 8 gate, 8 up
+// columns): out[row][j] = silu(sum_s gate) * (sum_s up), bf16 [rows][n2 / 2].
+void launch_swiglu_reduce(const float* slab, int nslab, int64_t slab_stride, int rows, int n2, bf16_t* out, hipStream_t s);

@@ -132,8 +132,24 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
     const int row = (int)(gw / slots), slot = (int)(gw % slots);
     const int u = p.row_utt ? p.row_utt[row] : row;
     const int pos = p.row_pos ? p.row_pos[row] : p.cur_len[u];
-    bf16_t* src = p.qkv + (int64_t)row * p.ld + (int64_t)slot * 128;
-    const uint32_t raw = *(const uint32_t*)(src + 2 * lane);
+    const int64_t src_off = (int64_t)row * p.ld + (int64_t)slot * 128 + 2 * lane;
+    float x0, x1;
+    uint32_t raw;
+    if (p.slab) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int z = 0; z < p.nslab; ++z) {
+            const float2 t = *(const float2*)(p.slab + z * p.slab_stride + src_off);
+            acc.x += t.x;
+            acc.y += t.y;
+        }
+        x0 = acc.x;
+        x1 = acc.y;
+        raw = pack_bf16x2(x0, x1);
+    } else {
+        raw = *(const uint32_t*)(p.qkv + src_off);
+        x0 = __uint_as_float(raw << 16);
+        x1 = __uint_as_float(raw & 0xffff0000u);
+    }
     if (slot >= p.heads + p.kv_heads) {  // V: cached as is
         const int kvh = slot - p.heads - p.kv_heads;
         *(uint32_t*)(p.vcache + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride + (int64_t)pos * 128 + 2 * lane) = raw;
@@ -141,7 +157,6 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
     }
     const bool is_q = slot < p.heads;
     const float* w = is_q ? p.q_norm_w : p.k_norm_w;
-    const float x0 = __uint_as_float(raw << 16), x1 = __uint_as_float(raw & 0xffff0000u);
     const float rstd = 1.0f / sqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.0f + p.eps);
     const float y0 = x0 * rstd * w[2 * lane], y1 = x1 * rstd * w[2 * lane + 1];
     float r0 = y0, r1 = y1;
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
     }
     const uint32_t packed = pack_bf16x2(r0, r1);
     if (is_q) {
-        *(uint32_t*)(src + 2 * lane) = packed;
+        *(uint32_t*)(p.q_out + (int64_t)row * p.q_ld + (int64_t)slot * 128 + 2 * lane) = packed;
     } else {
         const int kvh = slot - p.heads;
         *(uint32_t*)(p.kcache + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride + (int64_t)pos * 128 + 2 * lane) = packed;
@@ -363,7 +378,35 @@ __global__ __launch_bounds__(256) void step_kernel(StepParams p) {
     if (threadIdx.x == 0) *p.n_active = active;
 }
 
+__global__ __launch_bounds__(256) void swiglu_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t slab_stride,
+                                                            int rows, int n2, bf16_t* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 outputs
+    const int per_row = n2 >> 4;
+    if (idx >= (int64_t)rows * per_row) return;
+    const int row = (int)(idx / per_row), blk = (int)(idx % per_row);
+    float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < nslab; ++z) {
+        const float4* src = (const float4*)(slab + z * slab_stride + (int64_t)row * n2 + blk * 16);
+        const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+        g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
+        u[0] += c.x; u[1] += c.y; u[2] += c.z; u[3] += c.w; u[4] += d.x; u[5] += d.y; u[6] += d.z; u[7] += d.w;
+    }
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = g[j] / (1.0f + __expf(-g[j])) * u[j];
+    *(uint4*)(out + (int64_t)row * (n2 >> 1) + blk * 8) =
+        make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+}
+
 }  // namespace
+
+void launch_swiglu_reduce(const float* slab, int nslab, int64_t slab_stride, int rows, int n2, bf16_t* out, hipStream_t s) {
+    if (rows <= 0) return;
+    Q3_REQUIRE(n2 % 16 == 0, "swiglu_reduce: width must be a multiple of 16");
+    hipLaunchKernelGGL(swiglu_reduce_kernel, dim3(cdiv((int64_t)rows * (n2 >> 4), 256)), dim3(256), 0, s, slab, nslab, slab_stride,
+                       rows, n2, out);
+    HIP_CHECK(hipGetLastError());
+}
 
 void launch_conv1(const Conv1Params& p, hipStream_t s) {
     if (p.n_chunks <= 0) return;

@@ -107,12 +107,14 @@ MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>
     }
     r.t_stride = t_stride > 0 ? t_stride : ((tmax + 3) & ~3);
     Q3_REQUIRE(r.t_stride >= tmax, "mel: t_stride is smaller than the longest utterance's frame count");
+    double mel_bytes = 0;  // algorithmic traffic: samples in + returned frames out
+    for (int u = 0; u < b; ++u) mel_bytes += 4.0 * (double)r.n16[u] + 4.0 * MEL_NMELS * (double)r.frames[u];
     r.raw = c.get<float>((size_t)b * MEL_NMELS * r.t_stride);
     r.dmax = c.get<unsigned>(b);
     HIP_CHECK(hipMemsetAsync(r.dmax, 0, (size_t)b * 4, c.s));
     r.d_frames = c.up(r.frames);
     launch_mel(c.m->mel, d16, c.up(off16), c.up(r.n16), c.up(tile_utt), c.up(tile_f0), (int)tile_utt.size(), r.raw, r.t_stride,
-               r.dmax, c.s);
+               r.dmax, c.s, mel_bytes);
     return r;
 }
 
@@ -173,6 +175,8 @@ std::vector<int> run_encoder(Ctx& c, const float* mel, int t_stride, const unsig
             }
         }
         const int nc = (int)ch_utt.size();
+        double enc_attn_flops = 0;
+        for (auto& sq : seqs) enc_attn_flops += 4.0 * sq.len * sq.len * d;
         if (nc > 0 && ntok_g > 0) {
             for (int ch = 0; ch < nc; ++ch)
                 for (int oy = 0; oy < F3; ++oy)
@@ -221,7 +225,7 @@ std::vector<int> run_encoder(Ctx& c, const float* mel, int t_stride, const unsig
                 }
                 FlashParams fp{qkv, 3 * d, qkv + d, qkv + 2 * d, 3 * d, d / cfg.enc_heads, att, d, d_seqs, d_tiles, (int)tiles.size(),
                                cfg.enc_heads, 1, 1.0f / sqrtf((float)(d / cfg.enc_heads)), 0};
-                launch_flash_attn(fp, d / cfg.enc_heads, c.s);
+                launch_flash_attn(fp, d / cfg.enc_heads, c.s, enc_attn_flops);
                 {
                     GemmParams p = gp(c, att, d, L.out, ntok_g);
                     p.bias = L.out_b; p.out = h; p.ldo = d;
@@ -485,6 +489,8 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         }
         const AttnSeq* d_seqs = c.up(seqs);
         const AttnTile* d_tiles = c.up(tiles);
+        double prefill_attn_flops = 0;  // causal: half of the dense 4 S^2 D per head
+        for (auto& sq : seqs) prefill_attn_flops += 2.0 * sq.len * sq.len * hd * nh;
         for (int l = 0; l < cfg.layers; ++l) {
             const DecLayerW& L = m->dec[l];
             launch_rmsnorm(hid, L.in_norm, xn, R, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
@@ -493,12 +499,13 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 p.out = qkv; p.ldo = QKV;
                 launch_gemm(p, A_PLAIN, OUT_BF16, wf, -1, c.s);
             }
-            RopeParams rp{qkv, QKV, R, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
-                          m->rope_max_pos, d_row_utt, d_row_pos, st_len, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
+            RopeParams rp{qkv, QKV, nullptr, 0, 0, qkv, QKV, R, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half,
+                          cfg.rope_interleaved, m->rope_max_pos, d_row_utt, d_row_pos, st_len, kc + l * layer_stride, vc + l * layer_stride,
+                          utt_stride, head_stride};
             launch_rope(rp, c.s);
             FlashParams fp{qkv, QKV, kc + l * layer_stride, vc + l * layer_stride, hd, head_stride, att, (int64_t)nh * hd, d_seqs, d_tiles,
                            (int)tiles.size(), nh, nh / nkv, scale, 1};
-            launch_flash_attn(fp, hd, c.s);
+            launch_flash_attn(fp, hd, c.s, prefill_attn_flops);
             {
                 GemmParams p = gp(c, att, (int64_t)nh * hd, L.o, R);
                 p.out = hid; p.ldo = H;
@@ -527,47 +534,57 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
     {
         float* hd_ = c.get<float>((size_t)b * H);
         bf16_t* xn = c.get<bf16_t>((size_t)b * H);
-        bf16_t* qkv = c.get<bf16_t>((size_t)b * QKV);
+        bf16_t* qd = c.get<bf16_t>((size_t)b * nh * hd);
         bf16_t* att = c.get<bf16_t>((size_t)b * nh * hd);
         bf16_t* act = c.get<bf16_t>((size_t)b * cfg.inter);
+        // Few rows, wide weights: every projection is split along K so that >= 256 workgroups stream
+        // the weights; the partial sums are reduced by whichever kernel consumes them next.
+        const int dtile = b > 64 ? 2 : 1;  // 128x64 or 64x64
+        auto split_for = [&](int N, int K) {
+            const int tiles = cdiv(b, dtile == 2 ? 128 : 64) * cdiv(N, 64), nk = K / 64;
+            int ks = 1;
+            while (tiles * ks < 256 && ks * 2 <= nk / 4) ks *= 2;
+            return ks;
+        };
+        const int ks_qkv = split_for(QKV, H), ks_o = split_for(H, nh * hd), ks_gu = split_for(2 * cfg.inter, H), ks_dn = split_for(H, cfg.inter);
+        size_t slab_elems = (size_t)ks_qkv * b * QKV;
+        slab_elems = std::max(slab_elems, (size_t)ks_o * b * H);
+        slab_elems = std::max(slab_elems, (size_t)ks_gu * b * 2 * cfg.inter);
+        slab_elems = std::max(slab_elems, (size_t)ks_dn * b * H);
+        float* slab = c.get<float>(slab_elems);
+        auto slab_gemm = [&](const bf16_t* A, int64_t lda, const LinearW& W, int ks) {
+            GemmParams p = gp(c, A, lda, W, b);
+            p.out = slab; p.ldo = W.N; p.ksplit = ks; p.slab_stride = (int64_t)b * W.N;
+            launch_gemm(p, A_PLAIN, OUT_SLAB, wf, dtile, c.s);
+        };
         int active = b;
         HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
         HIP_CHECK(hipStreamSynchronize(c.s));
         for (int it = 1; it < max_tokens && active > 0; ++it) {
+            // K and V rows visible this step (counted as if no utterance has stopped yet)
+            double kv_bytes = 0;
+            for (int i = 0; i < b; ++i) kv_bytes += 2.0 * 2.0 * nkv * hd * (double)(utt_rows[i] + it);
             launch_embed_tokens(st_next, b, H, qemb ? nullptr : (const bf16_t*)m->embed.w, qemb ? (const uint32_t*)m->embed.w : nullptr,
                                 m->embed.scales, m->embed.biases, cfg.group_size, hd_, c.s);
             for (int l = 0; l < cfg.layers; ++l) {
                 const DecLayerW& L = m->dec[l];
-                launch_rmsnorm(hd_, L.in_norm, xn, b, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
-                {
-                    GemmParams p = gp(c, xn, H, L.qkv, b);
-                    p.out = qkv; p.ldo = QKV;
-                    launch_gemm(p, A_PLAIN, OUT_BF16, wf, -1, c.s);
-                }
-                RopeParams rp{qkv, QKV, b, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
-                              m->rope_max_pos, nullptr, nullptr, st_len, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
+                // residual += previous layer's down-projection partials, then input norm
+                launch_rmsnorm(hd_, L.in_norm, xn, b, H, cfg.rms_eps, nullptr, slab, l ? ks_dn : 0, (int64_t)b * H, c.s);
+                slab_gemm(xn, H, L.qkv, ks_qkv);
+                RopeParams rp{nullptr, QKV, slab, ks_qkv, (int64_t)b * QKV, qd, (int64_t)nh * hd, b, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps,
+                              m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos, nullptr, nullptr, st_len,
+                              kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
                 launch_rope(rp, c.s);
-                DecodeAttnParams dp{qkv, QKV, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride, st_len, 1, att,
+                DecodeAttnParams dp{qd, (int64_t)nh * hd, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride, st_len, 1, att,
                                     (int64_t)nh * hd, b, nkv, nh / nkv, scale};
-                launch_decode_attn(dp, hd, c.s);
-                {
-                    GemmParams p = gp(c, att, (int64_t)nh * hd, L.o, b);
-                    p.out = hd_; p.ldo = H;
-                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
-                }
-                launch_rmsnorm(hd_, L.post_norm, xn, b, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
-                {
-                    GemmParams p = gp(c, xn, H, L.gate_up, b);
-                    p.out = act; p.ldo = cfg.inter;
-                    launch_gemm(p, A_PLAIN, OUT_SWIGLU, wf, -1, c.s);
-                }
-                {
-                    GemmParams p = gp(c, act, cfg.inter, L.down, b);
-                    p.out = hd_; p.ldo = H;
-                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
-                }
+                launch_decode_attn(dp, hd, c.s, kv_bytes);
+                slab_gemm(att, (int64_t)nh * hd, L.o, ks_o);
+                launch_rmsnorm(hd_, L.post_norm, xn, b, H, cfg.rms_eps, nullptr, slab, ks_o, (int64_t)b * H, c.s);
+                slab_gemm(xn, H, L.gate_up, ks_gu);
+                launch_swiglu_reduce(slab, ks_gu, (int64_t)b * 2 * cfg.inter, b, 2 * cfg.inter, act, c.s);
+                slab_gemm(act, cfg.inter, L.down, ks_dn);
             }
-            launch_rmsnorm(hd_, m->final_norm, x_last, b, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
+            launch_rmsnorm(hd_, m->final_norm, x_last, b, H, cfg.rms_eps, nullptr, slab, ks_dn, (int64_t)b * H, c.s);
             lm_head(x_last, b, it);
             step(1);
             res->decode_steps += 1;

@@ -227,6 +227,15 @@ class Qwen3ASRModel:
             ms=dict(mel=res.ms_mel, encoder=res.ms_encoder, prefill=res.ms_prefill, decode=res.ms_decode),
             decode_steps=int(res.decode_steps), tokens_total=int(res.tokens_total), taps=taps)
 
+    # ---- per-kernel timing ----
+    def profile_start(self, stride=1):
+        _lib.check(self._lib, self._lib.q3asr_profile_start(self._h, int(stride)))
+
+    def profile_stop(self):
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.check(self._lib, self._lib.q3asr_profile_stop(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     # ---- kernel-level entry points (parity tests) ----
     def op_gemm(self, a_bits, w_bits, bias=None, gelu=False, tile=-1, ksplit=1):
         a_bits, w_bits = np.ascontiguousarray(a_bits, np.uint16), np.ascontiguousarray(w_bits, np.uint16)
