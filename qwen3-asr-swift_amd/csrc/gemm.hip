@@ -20,6 +20,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
+// LDS ring depth: the 128x128 tile keeps two 32 KB stages (two workgroups per CU); the smaller
+// tiles, used when few rows meet wide weights (decode), keep four so that three tiles of weights
+// are in flight per workgroup.
+constexpr int gemm_stages(int mt, int nt) { return (mt == 4 && nt == 4) ? 2 : 4; }
+
 struct ConvRow {
     int64_t base;
     int iy0, ix0, wv;
@@ -30,6 +35,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
     constexpr int AP = BM * 8 / 256, WP = BN * 8 / 256;  // 16-byte chunks per thread per tile
+    constexpr int STAGES = gemm_stages(MT, NT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,14 +170,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         }
     }
 
-    if (kt0 < kt1) {
-        stage(0, kt0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int cur = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
-            const char* sb = smem + cur * STAGE;
+    // STAGES-deep ring of LDS tiles.  Iteration t: wait until this wave's loads of tile t have
+    // landed (counted vmcnt: the STAGES-2 younger tiles stay in flight), barrier (now every wave's
+    // part of tile t is in LDS and every wave has finished reading tile t-1), refill the buffer
+    // tile t-1 occupied with tile t+STAGES-1, compute tile t.
+    constexpr int INFLIGHT = (STAGES - 2) * (AP + (WFMT == W_BF16 ? WP : 0));
+    static_assert(INFLIGHT <= 63, "vmcnt field overflow");
+    const int nt = kt1 - kt0;
+    if (nt > 0) {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nt) stage(s, kt0 + s);
+        for (int t = 0; t < nt; ++t) {
+            if (t + STAGES - 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + STAGES - 1 < nt) stage((t + STAGES - 1) % STAGES, kt0 + t + STAGES - 1);
+            const char* sb = smem + (t % STAGES) * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 wf[NT], af[MT];
@@ -185,9 +200,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                     for (int b = 0; b < NT; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], af[a], acc[a][b], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
         }
     }
 
@@ -288,7 +300,7 @@ template <int MT, int NT, int AMODE, int OUT, int WFMT>
 void launch_t(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = (size_t)gemm_stages(MT, NT) * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<MT, NT, AMODE, OUT, WFMT>,

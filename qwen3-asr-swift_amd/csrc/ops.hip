@@ -87,16 +87,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
                                                       bf16_t* __restrict__ out, int rows, int d, float eps,
                                                       const int* __restrict__ rowidx, const float* __restrict__ slab,
                                                       int nslab, int64_t slab_stride) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
+    // one workgroup per row: the decode step has few rows and up to 8 slabs each, so the row is
+    // spread over 256 threads to keep enough loads in flight
+    __shared__ float part[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
     const int64_t src = rowidx ? rowidx[row] : row;
     const int d4 = d >> 2;
     float4* x4 = (float4*)(x + src * d);
-    float4 v[8];
+    float4 v[2];
     float sq = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = lane + 64 * j;
+    for (int j = 0; j < 2; ++j) {
+        const int c = tid + 256 * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < d4) {
             v[j] = x4[c];
@@ -110,11 +112,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
         }
         sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + eps);
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) part[tid >> 6] = sq;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)d + eps);
     bf16_t* o = out + (int64_t)row * d;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = lane + 64 * j;
+    for (int j = 0; j < 2; ++j) {
+        const int c = tid + 256 * j;
         if (c < d4) {
             const float4 ww = ((const float4*)w)[c];
             *(uint2*)(o + 4 * c) = make_uint2(pack_bf16x2(v[j].x * rstd * ww.x, v[j].y * rstd * ww.y),
@@ -425,7 +430,7 @@ void launch_rmsnorm(float* x, const float* w, bf16_t* out, int rows, int d, floa
                     int nslab, int64_t slab_stride, hipStream_t s) {
     if (rows <= 0) return;
     Q3_REQUIRE(d % 4 == 0 && d <= 2048, "rmsnorm: width must be a multiple of 4 and <= 2048");
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, out, rows, d, eps, rowidx, slab, nslab,
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, s, x, w, out, rows, d, eps, rowidx, slab, nslab,
                        slab_stride);
     HIP_CHECK(hipGetLastError());
 }
