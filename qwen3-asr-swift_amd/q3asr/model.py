@@ -157,6 +157,10 @@ class Qwen3ASRModel:
         kw.update(overrides)
         m = cls(make_config(preset, **kw), device)
         m.load_checkpoint(load_dir(model_dir))
+        vocab = os.path.join(model_dir, "vocab.json")
+        if os.path.exists(vocab):                       # Qwen3ASR.swift:728-739
+            from .tokenizer import Qwen3Tokenizer
+            m.tokenizer = Qwen3Tokenizer.load(vocab)
         return m
 
     # ---- transcription ----

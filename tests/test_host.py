@@ -1,0 +1,194 @@
+"""CPU tests of the host layer: C-ABI exports, config image, weight naming, safetensors / WAV ingest,
+tokenizer, and the utterance sharding + gather over torch.distributed (gloo, world size 2)."""
+import ctypes
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from q3asr import make_config, synth
+from q3asr import lib as q3lib
+from q3asr.audio_io import AudioLoadError, load_wav, resample_linear
+from q3asr.config import Q3Config
+from q3asr.safetensors_io import load_dir, save_file
+from q3asr.shard import shard_utterances, utterance_cost
+from q3asr.tokenizer import Qwen3Tokenizer, TokenizerError
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "q3asr.h")).read()
+    declared = sorted(set(re.findall(r"\b(q3asr_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 13
+    so = ctypes.CDLL(q3lib.LIB_PATH)
+    assert [s for s in declared if not hasattr(so, s)] == []
+    assert sorted(q3lib.EXPORTS) == declared
+
+
+def test_config_struct_matches_header():
+    header = open(os.path.join(ROOT, "include", "q3asr.h")).read()
+    body = header[header.index("typedef struct q3asr_config {"):header.index("} q3asr_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if decl:
+            ctype, names = decl.split(None, 1)
+            fields += [(n.strip(), ctype) for n in names.split(",")]
+    want = [(n, "float" if t is ctypes.c_float else "int") for n, t in Q3Config._fields_]
+    assert fields == want
+    assert ctypes.sizeof(Q3Config) == 4 * len(want)
+
+
+def test_create_without_gpu_fails_loudly():
+    """No CPU fallback: on a box without a HIP device create() reports an error instead of a model."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = q3lib.load()
+    h = ctypes.c_void_p()
+    rc = lib.q3asr_create(ctypes.byref(make_config("tiny")), 0, ctypes.byref(h))
+    assert rc != 0 and not h.value
+    assert b"HIP" in lib.q3asr_last_error() or b"device" in lib.q3asr_last_error()
+
+
+# ---------------------------------------------------------------- weights
+def test_synthetic_checkpoint_uses_reference_key_names():
+    cfg = make_config("tiny")
+    ck = synth.make_checkpoint(cfg, seed=0)
+    want = {"audio_tower.conv2d1.weight", "audio_tower.conv_out.weight", "audio_tower.ln_post.bias", "audio_tower.proj2.bias",
+            "audio_tower.layers.1.self_attn.out_proj.bias", "audio_tower.layers.0.final_layer_norm.weight", "audio_tower.layers.0.fc1.weight",
+            "model.embed_tokens.weight", "model.norm.weight", "model.layers.1.self_attn.q_norm.weight",
+            "model.layers.0.post_attention_layernorm.weight", "model.layers.1.mlp.down_proj.weight"}
+    assert want <= set(ck)
+    assert ck["audio_tower.conv2d2.weight"][0].shape == (32, 3, 3, 32)         # [out, kH, kW, in]: WeightLoading.swift:277-284
+    assert ck["audio_tower.conv_out.weight"][0].shape == (128, 32 * 16)
+    q = synth.make_checkpoint(make_config("tiny", weight_format=1), seed=0)
+    assert q["model.layers.0.mlp.gate_proj.weight"][1] == "u32" and q["model.layers.0.mlp.gate_proj.weight"][0].shape == (512, 256 // 8)
+    assert q["model.embed_tokens.scales"][0].shape == (151936, 256 // 64)
+    assert "audio_tower.layers.0.fc1.scales" not in q                          # the encoder stays dense
+
+
+def test_safetensors_round_trip_and_bounds(tmp_path):
+    ck = {k: v for k, v in synth.make_checkpoint(make_config("tiny", weight_format=1), seed=2).items() if "layers.0." in k or "conv2d1" in k}
+    save_file(tmp_path / "model.safetensors", ck)
+    back = load_dir(str(tmp_path))
+    assert set(back) == set(ck)
+    for k, (arr, tag) in ck.items():
+        assert back[k][1] == tag and np.array_equal(back[k][0], arr)
+    raw = (tmp_path / "model.safetensors").read_bytes()
+    (tmp_path / "model.safetensors").write_bytes(struct.pack("<Q", 1 << 40) + raw[8:])
+    with pytest.raises(ValueError):
+        load_dir(str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        load_dir(str(tmp_path / "nothing") if (tmp_path / "nothing").mkdir() is None else "")
+
+
+# ---------------------------------------------------------------- WAV
+def _wav_stub(chunk_id, chunk_size, total):
+    """The malformed files of SecurityRegressionTests.swift:16-57."""
+    data = bytearray(total)
+    data[0:4], data[8:12] = b"RIFF", b"WAVE"
+    struct.pack_into("<HH", data, 20, 1, 1)
+    struct.pack_into("<I", data, 24, 24000)
+    struct.pack_into("<H", data, 34, 16)
+    data[36:40] = chunk_id
+    struct.pack_into("<I", data, 40, chunk_size)
+    return bytes(data)
+
+
+def test_wav_loader(tmp_path):
+    audio, rate = load_wav(os.path.join(GOLDEN, "test_audio.wav"))             # has a LIST chunk before "data"
+    assert rate == 24000 and audio.shape == (480000,) and audio.dtype == np.float32 and 0.5 < np.abs(audio).max() < 1.0
+    assert len(resample_linear(audio, 24000, 16000)) == 320000
+    for name, blob in (("bounds.wav", _wav_stub(b"JUNK", 0x7FFFFFF0, 64)), ("nodata.wav", _wav_stub(b"JUNK", 0, 64)),
+                       ("short.wav", b"RIFF")):
+        (tmp_path / name).write_bytes(blob)
+        with pytest.raises(AudioLoadError):
+            load_wav(str(tmp_path / name))
+
+
+# ---------------------------------------------------------------- tokenizer
+def test_tokenizer_toy_vocab_round_trip(tmp_path):
+    """The fixture of RealtimeTranslationTests.swift:112-143."""
+    vocab = {"H": 0, "e": 1, "l": 2, "o": 3, "Ġ": 4, "w": 5, "r": 6, "d": 7, "!": 8}
+    (tmp_path / "vocab.json").write_text(json.dumps(vocab), encoding="utf-8")
+    with pytest.raises(TokenizerError):
+        Qwen3Tokenizer.load(str(tmp_path / "vocab.json"))                     # merges.txt is required
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n", encoding="utf-8")
+    tok = Qwen3Tokenizer.load(str(tmp_path / "vocab.json"))
+    ids = tok.encode("Hello world!")
+    assert ids == [0, 1, 2, 2, 3, 4, 5, 3, 6, 2, 7, 8]
+    assert tok.decode(ids) == "Hello world!"
+
+
+def test_tokenizer_merges_specials_and_utf8(tmp_path):
+    vocab = {"l": 0, "o": 1, "w": 2, "lo": 3, "low": 4, "Ġ": 5, "Ġlow": 6, "Ã": 7, "©": 8, "<asr_text>": 20}
+    (tmp_path / "vocab.json").write_text(json.dumps(vocab), encoding="utf-8")
+    (tmp_path / "merges.txt").write_text("#version: 0.2\nl o\nlo w\nĠ low\n", encoding="utf-8")
+    cfg = {"added_tokens_decoder": {"30": {"content": "<|im_end|>"}, "31": {"content": "<|audio_pad|>"}}}
+    (tmp_path / "tokenizer_config.json").write_text(json.dumps(cfg), encoding="utf-8")
+    tok = Qwen3Tokenizer.load(str(tmp_path / "vocab.json"))
+    assert tok.encode("low low<asr_text>low<|im_end|>") == [4, 6, 20, 4, 30]
+    assert tok.decode([4, 6, 30, 20, 31, 4]) == "low low<asr_text>low"       # "<|...|>" dropped, "<asr_text>" kept
+    assert tok.decode([7, 8]) == "é"                                          # bytes C3 A9 split over two tokens
+    assert tok.post_process(tok.decode([4, 20, 6])) == "low"
+
+
+# ---------------------------------------------------------------- sharding
+def test_shard_balance_and_cover():
+    rng = np.random.default_rng(4321)
+    lengths = (rng.uniform(5, 300, size=203) * 16000).astype(int).tolist()
+    for world in (1, 2, 4, 8):
+        shards = shard_utterances(lengths, world)
+        assert sorted(i for s in shards for i in s) == list(range(len(lengths)))
+        loads = [sum(utterance_cost(lengths[i]) for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(utterance_cost(n) for n in lengths)
+        for s in shards:
+            costs = [utterance_cost(lengths[i]) for i in s]
+            assert costs == sorted(costs, reverse=True)                       # each rank's list is length-bucketed
+    assert utterance_cost(480000) == 390 + 15 + 448
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from q3asr.shard import transcribe_sharded
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    audios = [np.zeros(16000 * (1 + (i * 7) % 11), np.float32) + i for i in range(9)]
+    seen = []
+
+    def fake_transcribe(clips):                  # stands in for Qwen3ASRModel.transcribe_batch on this rank's GPU
+        seen.extend(int(c[0]) for c in clips)
+        return [[int(c[0])] * (int(c[0]) % 4) for c in clips]
+
+    tokens, audio_s, n_tok = transcribe_sharded(fake_transcribe, audios, rank, world, dist)
+    q.put((rank, seen, tokens, audio_s, n_tok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_transcribe_gathers_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = sorted(i for _, s, _, _, _ in out for i in s)
+    assert seen == list(range(9))                                             # every utterance on exactly one rank
+    want = [[i] * (i % 4) for i in range(9)]
+    for _, s, tokens, audio_s, n_tok in out:
+        assert tokens == want                                                 # every rank ends with every transcript
+        assert 0 < len(s) < 9
+        assert n_tok == sum(len(t) for t in want)
+        assert abs(audio_s - sum(1 + (i * 7) % 11 for i in range(9))) < 1e-9
