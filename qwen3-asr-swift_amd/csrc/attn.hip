@@ -11,7 +11,7 @@
 //
 // decode_attn_kernel: one new query per utterance against its KV cache (GQA group shares the
 // K/V stream).  HBM-bound: K rows go straight from global memory into MFMA A fragments, the
-// probabilities are exchanged through a few LDS words, V rows are consumed coalesced by the VALU.
+// probabilities are broadcast with v_readlane, V rows are consumed coalesced by the VALU.
 #include "attn.h"
 #include "prof.h"
 
@@ -157,8 +157,6 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
 template <int GROUP>
 __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     constexpr int D = 128;
-    __shared__ float pl[4][GROUP][16];
-    __shared__ float al[4][GROUP];
     __shared__ float sm_m[4][GROUP], sm_l[4][GROUP];
     __shared__ float so[4][GROUP][D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -178,63 +176,74 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     float o[GROUP][2];
 #pragma unroll
     for (int q = 0; q < GROUP; ++q) o[q][0] = o[q][1] = 0.f;
-    volatile float* vpl = &pl[wave][0][0];
-    volatile float* val = &al[wave][0];
 
-    const int ntiles = (len + 15) >> 4;
-    for (int t = wave; t < ntiles; t += 4) {
-        const int kv0 = t * 16;
-        const int key = min(kv0 + li, len - 1);
-        Frag kf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[ks].u = *(const uint4*)(Kb + (int64_t)key * D + 32 * ks + 8 * lg);
-        uint32_t vv[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) vv[k] = *(const uint32_t*)(Vb + (int64_t)min(kv0 + k, len - 1) * D + 2 * lane);
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks].v, qf[ks].v, s, 0, 0, 0);
-        float sv[4], tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sv[r] = (kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;
-            tmax = fmaxf(tmax, sv[r]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = exp2f(m - m_new);
-        float pr[4], ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pr[r] = exp2f(sv[r] - m_new);
-            ps += pr[r];
-        }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        l = l * alpha + ps;
-        m = m_new;
-        if (li < GROUP) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vpl[li * 16 + 4 * lg + r] = pr[r];
-            if (lg == 0) val[li] = alpha;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < GROUP; ++q) {
-            const float a = val[q];
-            float ox = o[q][0] * a, oy = o[q][1] * a;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float pk = vpl[q * 16 + k];
-                ox = fmaf(pk, __uint_as_float(vv[k] << 16), ox);
-                oy = fmaf(pk, __uint_as_float(vv[k] & 0xffff0000u), oy);
-            }
-            o[q][0] = ox;
-            o[q][1] = oy;
-        }
-        __builtin_amdgcn_wave_barrier();
+    // Tiles of 16 keys, round-robin over the four waves.  The next tile's K fragments and V rows are
+    // requested before the current tile is consumed, so every wave keeps two tiles (16 KB) in flight.
+    // Loads use one base address per tile plus immediate offsets (no per-row clamping).
+#define DA_LOAD(KF, VV, T)                                                                                     \
+    {                                                                                                          \
+        const int kv0_ = (T) * 16;                                                                             \
+        /* rows past len-1 are allocated padding (the cache holds 16 spare rows); they are masked below */    \
+        const bf16_t* kp_ = Kb + (int64_t)(kv0_ + li) * D + 8 * lg;                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) KF[ks].u = *(const uint4*)(kp_ + 32 * ks);            \
+        const bf16_t* vp_ = Vb + (int64_t)kv0_ * D + 2 * lane;                                                 \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) VV[k] = *(const uint32_t*)(vp_ + k * D);                \
     }
+#define DA_COMPUTE(KF, VV, T)                                                                                  \
+    {                                                                                                          \
+        const int kv0 = (T) * 16;                                                                              \
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KF[ks].v, qf[ks].v, s, 0, 0, 0);                       \
+        float sv[4], tmax = -INFINITY;                                                                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
+            sv[r] = (kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;                                         \
+            tmax = fmaxf(tmax, sv[r]);                                                                         \
+        }                                                                                                      \
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));                                                          \
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                                                          \
+        const float m_new = fmaxf(m, tmax);                                                                    \
+        const float alpha = exp2f(m - m_new);                                                                  \
+        float pr[4], ps = 0.f;                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
+            pr[r] = exp2f(sv[r] - m_new);                                                                      \
+            ps += pr[r];                                                                                       \
+        }                                                                                                      \
+        ps += __shfl_xor(ps, 16, 64);                                                                          \
+        ps += __shfl_xor(ps, 32, 64);                                                                          \
+        l = l * alpha + ps;                                                                                    \
+        m = m_new;                                                                                             \
+        /* lane (q + 16 g) holds the probabilities of keys 4 g .. 4 g + 3 for query q: broadcast them */       \
+        _Pragma("unroll") for (int q = 0; q < GROUP; ++q) {                                                    \
+            const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), q));               \
+            float ox = o[q][0] * a, oy = o[q][1] * a;                                                          \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                   \
+                const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr[k & 3]), q + 16 * (k >> 2))); \
+                const uint32_t vk = (kv0 + k < len) ? VV[k] : 0u;                                              \
+                ox = fmaf(pk, __uint_as_float(vk << 16), ox);                                                  \
+                oy = fmaf(pk, __uint_as_float(vk & 0xffff0000u), oy);                                          \
+            }                                                                                                  \
+            o[q][0] = ox;                                                                                      \
+            o[q][1] = oy;                                                                                      \
+        }                                                                                                      \
+    }
+    const int ntiles = (len + 15) >> 4;
+    Frag kfA[4], kfB[4];
+    uint32_t vvA[16], vvB[16];
+    int t = wave;
+    if (t < ntiles) DA_LOAD(kfA, vvA, t);
+    while (t < ntiles) {
+        const int t2 = t + 4;
+        if (t2 < ntiles) DA_LOAD(kfB, vvB, t2);
+        DA_COMPUTE(kfA, vvA, t);
+        if (t2 >= ntiles) break;
+        const int t3 = t2 + 4;
+        if (t3 < ntiles) DA_LOAD(kfA, vvA, t3);
+        DA_COMPUTE(kfB, vvB, t2);
+        t = t3;
+    }
+#undef DA_LOAD
+#undef DA_COMPUTE
     if (li < GROUP && lg == 0) {
         sm_m[wave][li] = m;
         sm_l[wave][li] = l;

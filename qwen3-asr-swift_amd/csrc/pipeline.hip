@@ -393,6 +393,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         if (res->n_audio_tokens) res->n_audio_tokens[u] = ntok[i];
     }
     const int R = (int)ids.size();
+    cap += 16;  // spare rows: the decode-attention kernel reads whole 16-key tiles
     Q3_REQUIRE(cap <= m->rope_max_pos, "transcribe: prompt + max_tokens exceeds the RoPE table");
     Q3_REQUIRE(cfg.enc_out_dim == H, "transcribe: encoder output dim must equal decoder hidden size");
 
@@ -539,11 +540,17 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         bf16_t* act = c.get<bf16_t>((size_t)b * cfg.inter);
         // Few rows, wide weights: every projection is split along K so that >= 256 workgroups stream
         // the weights; the partial sums are reduced by whichever kernel consumes them next.
-        const int dtile = b > 64 ? 2 : 1;  // 128x64 or 64x64
+        // 64x64 tiles up to 64 rows, 128x64 beyond (measured faster than 128x128 at 256 and 512 rows);
+        // Q3ASR_DECODE_TILE / Q3ASR_SPLIT_TARGET override the choice for tuning runs.
+        const char* env_tile = getenv("Q3ASR_DECODE_TILE");
+        const char* env_split = getenv("Q3ASR_SPLIT_TARGET");
+        const int dtile = env_tile ? atoi(env_tile) : (b > 64 ? 2 : 1);
+        const int split_target = env_split ? atoi(env_split) : 256;
+        const int tile_m = dtile == 1 ? 64 : 128, tile_n = dtile == 0 ? 128 : 64;
         auto split_for = [&](int N, int K) {
-            const int tiles = cdiv(b, dtile == 2 ? 128 : 64) * cdiv(N, 64), nk = K / 64;
+            const int tiles = cdiv(b, tile_m) * cdiv(N, tile_n), nk = K / 64;
             int ks = 1;
-            while (tiles * ks < 256 && ks * 2 <= nk / 4) ks *= 2;
+            while (tiles * ks < split_target && ks * 2 <= nk / 4) ks *= 2;
             return ks;
         };
         const int ks_qkv = split_for(QKV, H), ks_o = split_for(H, nh * hd), ks_gu = split_for(2 * cfg.inter, H), ks_dn = split_for(H, cfg.inter);
@@ -580,6 +587,8 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 launch_decode_attn(dp, hd, c.s, kv_bytes);
                 slab_gemm(att, (int64_t)nh * hd, L.o, ks_o);
                 launch_rmsnorm(hd_, L.post_norm, xn, b, H, cfg.rms_eps, nullptr, slab, ks_o, (int64_t)b * H, c.s);
+                // (a SwiGLU epilogue on the 64x128 tile measured slower here than partials + this reduce:
+                // four row tiles re-read the 50 MB gate/up weights)
                 slab_gemm(xn, H, L.gate_up, ks_gu);
                 launch_swiglu_reduce(slab, ks_gu, (int64_t)b * 2 * cfg.inter, b, 2 * cfg.inter, act, c.s);
                 slab_gemm(act, cfg.inter, L.down, ks_dn);
