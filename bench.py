@@ -64,6 +64,21 @@ def cpu_baseline(cfg, ck, audio, decode_steps):
     }
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE doubled as gfx950
+    needs, plus WRITE_SIZE; the passes cannot run inside this process).  Only a summary taken on this exact
+    workload counts; anything else reports None."""
+    import glob
+    if args.preset != "1.7b" or args.max_tokens != 448 or args.clip_seconds != 30.0:
+        return None, None
+    short = kernel.split("<")[0].replace("_kernel", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{short}_b{args.batch}.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,8 +90,9 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=448)
     ap.add_argument("--no-stop-rules", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-decode-steps", type=int, default=8)
-    ap.add_argument("--profile-stride", type=int, default=16)
+    ap.add_argument("--cpu-decode-steps", type=int, default=128)
+    ap.add_argument("--profile-stride", type=int, default=17, help="time every n-th launch with HIP events (odd, so that the "
+                    "samples walk through the per-layer launch pattern)")
     args = ap.parse_args()
 
     import torch
@@ -144,6 +160,7 @@ def main():
         else:
             ach, peak, unit, bound = per_launch_work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
         ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
+        traffic, traffic_src = pmc_traffic(top["name"], args)
         line = {
             "metric": "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips", "value": round(audio_s / dt, 2),
             "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -155,7 +172,7 @@ def main():
                        "clips_per_gpu": args.batch, "tokens_per_clip": round(tokens / (world * args.batch * args.steps), 1),
                        "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}"},
             "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                         "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
                          "work_per_launch": per_launch_work, "share_of_device_time": round(top["ms_est"] / sum(p["ms_est"] for p in prof), 3)},
             "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
                          "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:8]],
