@@ -115,6 +115,11 @@ int q3asr_profile_stop(q3asr_model* m, char* json_out, int capacity);
  * q3asr_op_gemm: out[M][N] fp32 = act(A[M][K] * W[N][K]^T + bias), bf16 operands; tile / ksplit select the kernel variant. */
 int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const float* bias, int M, int N, int K, int gelu,
                   int tile, int ksplit, float* out);
+/* q3asr_op_gemm_time: average milliseconds per launch of the GEMM kernel variant (tile: 0 128x128, 1 64x64, 2 128x64,
+ * 3 256x256, -1 automatic; out_kind: 0 bf16, 1 f32, 2 f32 accumulate, 3 SwiGLU, 4 argmax partials, 5 split-K slabs) on
+ * device-resident pseudo-random bf16 operands, HIP events on the model's stream.  A measurement hook with no
+ * counterpart in the reference (MLX's matmul is a library call there, QuantizedTextDecoder.swift:54-67). */
+int q3asr_op_gemm_time(q3asr_model* m, int M, int N, int K, int tile, int ksplit, int out_kind, int iters, float* ms_per_call);
 /* q3asr_op_gemm_q4: the dequant-fused variant, MLX affine 4-bit weights (QuantizedTextDecoder.swift:54-67). */
 int q3asr_op_gemm_q4(q3asr_model* m, const uint16_t* a, const uint32_t* wq, const uint16_t* scales, const uint16_t* biases,
                      int M, int N, int K, int tile, float* out);

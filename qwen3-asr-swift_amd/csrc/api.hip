@@ -183,6 +183,44 @@ int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const fl
     Q3_API_END
 }
 
+int q3asr_op_gemm_time(q3asr_model* m, int M, int N, int K, int tile, int ksplit, int out_kind, int iters, float* ms_per_call) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && ms_per_call && iters > 0 && out_kind >= 0 && out_kind <= 5, "op_gemm_time: bad argument");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    const int ks = std::max(1, ksplit);
+    bf16_t* da = m->arena.get<bf16_t>((size_t)M * K);
+    bf16_t* dw = m->arena.get<bf16_t>((size_t)N * K);
+    float* dout = m->arena.get<float>((size_t)M * N * ks);
+    launch_fill_bf16(da, (size_t)M * K, 0x1234u, m->stream);
+    launch_fill_bf16(dw, (size_t)N * K, 0x9876u, m->stream);
+    HIP_CHECK(hipMemsetAsync(dout, 0, (size_t)M * N * ks * 4, m->stream));
+    GemmParams p;
+    p.A = da; p.lda = K; p.W = dw; p.M = M; p.N = N; p.K = K; p.zero = m->zero_page;
+    p.out = dout; p.ldo = out_kind == OUT_SWIGLU ? N / 2 : N;
+    if (out_kind == OUT_SLAB) { p.ksplit = ks; p.slab_stride = (int64_t)M * N; }
+    int use_tile = tile < 0 ? gemm_pick_tile(M, N) : tile;
+    if (out_kind == OUT_ARGMAX) {
+        p.nparts = gemm_argmax_parts(N, use_tile == 2 ? 1 : use_tile);
+        p.part_val = m->arena.get<float>((size_t)M * p.nparts);
+        p.part_idx = m->arena.get<int>((size_t)M * p.nparts);
+    }
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch_gemm(p, A_PLAIN, (GemmOut)out_kind, W_BF16, use_tile, m->stream);
+    HIP_CHECK(hipEventRecord(e0, m->stream));
+    for (int i = 0; i < iters; ++i) launch_gemm(p, A_PLAIN, (GemmOut)out_kind, W_BF16, use_tile, m->stream);
+    HIP_CHECK(hipEventRecord(e1, m->stream));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_call = ms / iters;
+    Q3_API_END
+}
+
 int q3asr_op_gemm_q4(q3asr_model* m, const uint16_t* a, const uint32_t* wq, const uint16_t* scales, const uint16_t* biases,
                      int M, int N, int K, int tile, float* out) {
     Q3_API_BEGIN

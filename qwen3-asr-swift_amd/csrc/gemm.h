@@ -40,8 +40,11 @@ struct GemmParams {
     int64_t slab_stride = 0;
 };
 
-// tile: 0 -> 128x128, 1 -> 64x64, 2 -> 128x64 (BM x BN); -1 -> pick by shape
+// tile: 0 -> 128x128, 1 -> 64x64, 2 -> 128x64, 3 -> 256x256 (BM x BN; 3 needs plain rows and bf16 weights);
+// -1 -> pick by shape
 void launch_gemm(const GemmParams& p, GemmAMode amode, GemmOut out, GemmWFmt wfmt, int tile, hipStream_t s);
+// the 256x256 8-wave kernel (gemm256.hip); reached through launch_gemm
+void launch_gemm256(const GemmParams& p, GemmOut out, hipStream_t s);
 // number of 16*NT-column partial blocks the OUT_ARGMAX epilogue writes per row for a given N / tile
 int gemm_argmax_parts(int N, int tile);
 int gemm_pick_tile(int M, int N);

@@ -343,12 +343,20 @@ void launch_out(const GemmParams& p, GemmOut out, int tile, hipStream_t s) {
 }  // namespace
 
 int gemm_pick_tile(int M, int N) {
+    // Q3ASR_FORCE_TILE pins the automatic choice (parity tests run small models through every tile)
+    if (const char* f = getenv("Q3ASR_FORCE_TILE")) {
+        const int t = atoi(f);
+        if (t >= 0 && t <= 3) return t;
+    }
+    const int64_t t256 = (int64_t)cdiv(M, 256) * cdiv(N, 256);
+    if (t256 >= 224) return 3;  // about one workgroup per CU or more
     const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
     if (t128 >= 384) return 0;
     return 1;
 }
 
 int gemm_argmax_parts(int N, int tile) {
+    if (tile == 3) return cdiv(N, 256) * 4;
     const int bn = (tile == 0) ? 128 : 64;
     return cdiv(N, bn) * 2;
 }
@@ -362,7 +370,17 @@ void launch_gemm(const GemmParams& p, GemmAMode amode, GemmOut out, GemmWFmt wfm
     if (wfmt == W_Q4) Q3_REQUIRE(p.qgroup == 64 && p.K % 64 == 0, "gemm: q4 needs group 64 and K multiple of 64");
     if (out == OUT_SWIGLU) Q3_REQUIRE(p.N % 16 == 0, "gemm: SwiGLU needs N multiple of 16");
     if (out != OUT_SLAB) Q3_REQUIRE(p.ksplit == 1, "gemm: split-K only with slab output");
-    if (tile < 0) tile = gemm_pick_tile(p.M, p.N);
+    const bool can256 = amode == A_PLAIN && wfmt == W_BF16;
+    if (tile < 0) {
+        tile = gemm_pick_tile(p.M, p.N);
+        if (tile == 3 && !can256) tile = 0;
+    }
+    if (tile == 3) {
+        Q3_REQUIRE(can256, "gemm: the 256x256 tile needs plain rows and bf16 weights");
+        if (out == OUT_ARGMAX) Q3_REQUIRE(p.nparts == gemm_argmax_parts(p.N, 3), "gemm: nparts mismatch");
+        launch_gemm256(p, out, s);
+        return;
+    }
     if (out == OUT_SWIGLU && tile == 1) tile = 2;
     if (out == OUT_ARGMAX) Q3_REQUIRE(p.nparts == gemm_argmax_parts(p.N, tile == 2 ? 1 : tile), "gemm: nparts mismatch");
     if (amode == A_PLAIN) {

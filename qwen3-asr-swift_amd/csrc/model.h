@@ -111,6 +111,11 @@ struct q3asr_model {
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_max_pos = 0;
     BlockArena arena;  // per-call workspace
+    // decode-step GEMM variants (tile, split-K) per projection, measured once per batch size
+    struct DecodePlan {
+        int tile[4], ks[4];  // qkv, o, gate_up, down
+    };
+    std::map<int, DecodePlan> decode_plans;
 
     template <class T>
     T* dalloc(size_t count) {

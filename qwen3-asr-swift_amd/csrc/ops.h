@@ -99,3 +99,6 @@ void launch_step(const StepParams& p, hipStream_t s);
 // SwiGLU over split-K partial sums of the interleaved gate/up projection (blocks of 8 gate, 8 up
 // columns): out[row][j] = silu(sum_s gate) * (sum_s up), bf16 [rows][n2 / 2].
 void launch_swiglu_reduce(const float* slab, int nslab, int64_t slab_stride, int rows, int n2, bf16_t* out, hipStream_t s);
+
+// Pseudo-random bf16 values in (-1, 1) for the kernel timing entry points.
+void launch_fill_bf16(bf16_t* p, size_t n, uint32_t seed, hipStream_t s);

@@ -481,3 +481,19 @@ void launch_step(const StepParams& p, hipStream_t s) {
     hipLaunchKernelGGL(step_kernel, dim3(1), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
+
+namespace {
+__global__ void fill_bf16_kernel(bf16_t* p, size_t n, uint32_t seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (uint32_t)i * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    p[i] = f32_to_bf16((float)(h >> 8) * (2.0f / 16777216.0f) - 1.0f);
+}
+}  // namespace
+
+void launch_fill_bf16(bf16_t* p, size_t n, uint32_t seed, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, seed);
+    HIP_CHECK(hipGetLastError());
+}

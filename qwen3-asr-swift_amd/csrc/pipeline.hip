@@ -324,6 +324,65 @@ void model_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t*
 // ------------------------------------------------------------------------------------------ transcribe
 namespace {
 
+// The decode-step projections run b rows against wide weights, where the best (tile, split-K)
+// pair depends on b and on the projection's shape.  Once per batch size, every candidate is timed on
+// layer 0's own weights with pseudo-random activations, and a split is charged for its partial-sum
+// slabs (written once, read once by the consumer kernel).  Q3ASR_DECODE_TILE / Q3ASR_DECODE_SPLIT
+// pin one candidate for tuning runs.
+q3asr_model::DecodePlan decode_plan(Ctx& c, int b, GemmWFmt wf) {
+    q3asr_model* m = c.m;
+    const auto hit = m->decode_plans.find(b);
+    if (hit != m->decode_plans.end()) return hit->second;
+    const DecLayerW& L = m->dec[0];
+    const LinearW* W[4] = {&L.qkv, &L.o, &L.gate_up, &L.down};
+    q3asr_model::DecodePlan plan;
+    const char* env_tile = getenv("Q3ASR_DECODE_TILE");
+    const char* env_split = getenv("Q3ASR_DECODE_SPLIT");
+    int max_n = 0, max_k = 0;
+    for (auto* w : W) { max_n = std::max(max_n, w->N); max_k = std::max(max_k, w->K); }
+    const auto mark = m->arena.mark();
+    bf16_t* A = c.get<bf16_t>((size_t)b * max_k);
+    float* slab = c.get<float>((size_t)8 * b * max_n);
+    launch_fill_bf16(A, (size_t)b * max_k, 0x51u, c.s);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    constexpr int REPS = 8;
+    for (int g = 0; g < 4; ++g) {
+        plan.tile[g] = b > 64 ? 2 : 1;
+        plan.ks[g] = 1;
+        double best = 1e30;
+        for (int tile : {1, 2, 0, 3}) {
+            if ((tile == 3 && (wf != W_BF16 || b <= 128)) || (tile == 1 && b > 128)) continue;
+            if (env_tile && atoi(env_tile) != tile) continue;
+            for (int ks : {1, 2, 4, 8}) {
+                if (ks > 1 && ks * 4 > W[g]->K / 64) continue;  // at least four K tiles per split
+                if (env_split && atoi(env_split) != ks) continue;
+                GemmParams p = gp(c, A, W[g]->K, *W[g], b);
+                p.out = slab; p.ldo = W[g]->N; p.ksplit = ks; p.slab_stride = (int64_t)b * W[g]->N;
+                for (int i = 0; i < 2; ++i) launch_gemm(p, A_PLAIN, OUT_SLAB, wf, tile, c.s);
+                HIP_CHECK(hipEventRecord(e0, c.s));
+                for (int i = 0; i < REPS; ++i) launch_gemm(p, A_PLAIN, OUT_SLAB, wf, tile, c.s);
+                HIP_CHECK(hipEventRecord(e1, c.s));
+                HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0;
+                HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                const double slab_us = 2.0 * ks * b * (double)W[g]->N * 4.0 / 3.0e6;  // at ~3 TB/s
+                const double us = ms * 1000.0 / REPS + slab_us;
+                if (us < best) { best = us; plan.tile[g] = tile; plan.ks[g] = ks; }
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    m->arena.restore(mark);
+    if (getenv("Q3ASR_VERBOSE"))
+        fprintf(stderr, "q3asr: decode plan for %d rows (tile/split): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n", b, plan.tile[0],
+                plan.ks[0], plan.tile[1], plan.ks[1], plan.tile[2], plan.ks[2], plan.tile[3], plan.ks[3]);
+    m->decode_plans[b] = plan;
+    return plan;
+}
+
 struct Events {
     hipEvent_t e[5];
     Events() { for (auto& x : e) HIP_CHECK(hipEventCreate(&x)); }
@@ -426,7 +485,8 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         for (int i = 0; i < b; ++i) memcpy(&f[(size_t)i * max_tokens], req->forced_tokens + (size_t)idx[i] * max_tokens, (size_t)max_tokens * 4);
         d_forced = c.up(f);
     }
-    const int head_tile = 0;
+    int head_tile = gemm_pick_tile(b, cfg.vocab);  // 256x256 once the batch fills more than half of its rows
+    if (head_tile == 1 || (head_tile == 3 && (wf != W_BF16 || (b <= 128 && !getenv("Q3ASR_FORCE_TILE"))))) head_tile = 0;
     const int nparts = gemm_argmax_parts(cfg.vocab, head_tile);
     float* part_val = c.get<float>((size_t)b * nparts);
     int* part_idx = c.get<int>((size_t)b * nparts);
@@ -538,31 +598,20 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         bf16_t* qd = c.get<bf16_t>((size_t)b * nh * hd);
         bf16_t* att = c.get<bf16_t>((size_t)b * nh * hd);
         bf16_t* act = c.get<bf16_t>((size_t)b * cfg.inter);
-        // Few rows, wide weights: every projection is split along K so that >= 256 workgroups stream
-        // the weights; the partial sums are reduced by whichever kernel consumes them next.
-        // 64x64 tiles up to 64 rows, 128x64 beyond (measured faster than 128x128 at 256 and 512 rows);
-        // Q3ASR_DECODE_TILE / Q3ASR_SPLIT_TARGET override the choice for tuning runs.
-        const char* env_tile = getenv("Q3ASR_DECODE_TILE");
-        const char* env_split = getenv("Q3ASR_SPLIT_TARGET");
-        const int dtile = env_tile ? atoi(env_tile) : (b > 64 ? 2 : 1);
-        const int split_target = env_split ? atoi(env_split) : 256;
-        const int tile_m = dtile == 1 ? 64 : 128, tile_n = dtile == 0 ? 128 : 64;
-        auto split_for = [&](int N, int K) {
-            const int tiles = cdiv(b, tile_m) * cdiv(N, tile_n), nk = K / 64;
-            int ks = 1;
-            while (tiles * ks < split_target && ks * 2 <= nk / 4) ks *= 2;
-            return ks;
-        };
-        const int ks_qkv = split_for(QKV, H), ks_o = split_for(H, nh * hd), ks_gu = split_for(2 * cfg.inter, H), ks_dn = split_for(H, cfg.inter);
+        // Few rows, wide weights: every projection may be split along K so that enough workgroups
+        // stream the weights; the partial sums are reduced by whichever kernel consumes them next.
+        // The (tile, split) pair of each projection is measured once per batch size.
+        const q3asr_model::DecodePlan plan = decode_plan(c, b, wf);
+        const int ks_qkv = plan.ks[0], ks_o = plan.ks[1], ks_gu = plan.ks[2], ks_dn = plan.ks[3];
         size_t slab_elems = (size_t)ks_qkv * b * QKV;
         slab_elems = std::max(slab_elems, (size_t)ks_o * b * H);
         slab_elems = std::max(slab_elems, (size_t)ks_gu * b * 2 * cfg.inter);
         slab_elems = std::max(slab_elems, (size_t)ks_dn * b * H);
         float* slab = c.get<float>(slab_elems);
-        auto slab_gemm = [&](const bf16_t* A, int64_t lda, const LinearW& W, int ks) {
+        auto slab_gemm = [&](const bf16_t* A, int64_t lda, const LinearW& W, int which) {
             GemmParams p = gp(c, A, lda, W, b);
-            p.out = slab; p.ldo = W.N; p.ksplit = ks; p.slab_stride = (int64_t)b * W.N;
-            launch_gemm(p, A_PLAIN, OUT_SLAB, wf, dtile, c.s);
+            p.out = slab; p.ldo = W.N; p.ksplit = plan.ks[which]; p.slab_stride = (int64_t)b * W.N;
+            launch_gemm(p, A_PLAIN, OUT_SLAB, wf, plan.tile[which], c.s);
         };
         int active = b;
         HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
@@ -577,7 +626,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 const DecLayerW& L = m->dec[l];
                 // residual += previous layer's down-projection partials, then input norm
                 launch_rmsnorm(hd_, L.in_norm, xn, b, H, cfg.rms_eps, nullptr, slab, l ? ks_dn : 0, (int64_t)b * H, c.s);
-                slab_gemm(xn, H, L.qkv, ks_qkv);
+                slab_gemm(xn, H, L.qkv, 0);
                 RopeParams rp{nullptr, QKV, slab, ks_qkv, (int64_t)b * QKV, qd, (int64_t)nh * hd, b, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps,
                               m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos, nullptr, nullptr, st_len,
                               kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
@@ -585,13 +634,13 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 DecodeAttnParams dp{qd, (int64_t)nh * hd, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride, st_len, 1, att,
                                     (int64_t)nh * hd, b, nkv, nh / nkv, scale};
                 launch_decode_attn(dp, hd, c.s, kv_bytes);
-                slab_gemm(att, (int64_t)nh * hd, L.o, ks_o);
+                slab_gemm(att, (int64_t)nh * hd, L.o, 1);
                 launch_rmsnorm(hd_, L.post_norm, xn, b, H, cfg.rms_eps, nullptr, slab, ks_o, (int64_t)b * H, c.s);
                 // (a SwiGLU epilogue on the 64x128 tile measured slower here than partials + this reduce:
                 // four row tiles re-read the 50 MB gate/up weights)
-                slab_gemm(xn, H, L.gate_up, ks_gu);
+                slab_gemm(xn, H, L.gate_up, 2);
                 launch_swiglu_reduce(slab, ks_gu, (int64_t)b * 2 * cfg.inter, b, 2 * cfg.inter, act, c.s);
-                slab_gemm(act, cfg.inter, L.down, ks_dn);
+                slab_gemm(act, cfg.inter, L.down, 3);
             }
             launch_rmsnorm(hd_, m->final_norm, x_last, b, H, cfg.rms_eps, nullptr, slab, ks_dn, (int64_t)b * H, c.s);
             lm_head(x_last, b, it);

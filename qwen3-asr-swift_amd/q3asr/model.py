@@ -250,6 +250,12 @@ class Qwen3ASRModel:
                                                       M, N, K, int(gelu), tile, ksplit, out.ctypes.data))
         return out
 
+    def op_gemm_time(self, M, N, K, tile=-1, ksplit=1, out_kind=0, iters=20):
+        """Average ms per launch of one GEMM kernel variant on device-resident random operands."""
+        ms = ctypes.c_float()
+        _lib.check(self._lib, self._lib.q3asr_op_gemm_time(self._h, M, N, K, tile, ksplit, out_kind, iters, ctypes.byref(ms)))
+        return ms.value
+
     def op_gemm_q4(self, a_bits, wq, scales_bits, biases_bits, tile=-1):
         a_bits = np.ascontiguousarray(a_bits, np.uint16)
         wq = np.ascontiguousarray(wq, np.uint32)

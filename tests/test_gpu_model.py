@@ -78,6 +78,28 @@ def test_transcribe_teacher_forced_logits(variant):
         m.close()
 
 
+@pytest.mark.parametrize("tile", ["0", "2", "3"])
+def test_every_gemm_tile_through_the_model(tiny_model, tile, monkeypatch):
+    """The automatic tile choice depends on the row count, so a small model never reaches the large tiles on its
+    own: pin each tile in turn and run the encoder, the prefill epilogues (bf16, residual add, SwiGLU) and the
+    fused LM-head argmax through it."""
+    m, cfg, ck = tiny_model
+    monkeypatch.setenv("Q3ASR_FORCE_TILE", tile)
+    audio = synth.synth_audio(16000 * 3 + 1234, 5)
+    steps = 6
+    toks, ref_logits, stages = _oracle_run(cfg, ck, audio, steps)
+    forced = np.zeros((1, steps), dtype=np.int32)
+    forced[0, :len(toks)] = toks
+    out = m.transcribe_batch([audio], 16000, max_tokens=steps, forced_tokens=forced, tap_steps=steps, tap_embeds=True)
+    n_a = int(out.n_audio_tokens[0])
+    assert _rel(out.taps["audio_embeds"][:n_a], stages["audio_embeds"]) <= ENC_RTOL
+    assert _rel(out.taps["logits"][0, :len(toks)], ref_logits[:len(toks)]) <= LOGIT_RTOL
+    audios = [synth.synth_audio(n, 50 + i) for i, n in enumerate((16000, 40000, 52345))]
+    a = m.transcribe_batch(audios, 16000, max_tokens=8, stop_rules=False)
+    b = m.transcribe_batch(audios, 16000, max_tokens=8, stop_rules=False, tap_steps=8)
+    assert a.tokens == b.tokens
+
+
 def test_fused_argmax_equals_logit_tap(tiny_model):
     """The LM-head + argmax epilogue must pick the same ids as argmax over the tapped fp32 logits."""
     m, cfg, _ = tiny_model

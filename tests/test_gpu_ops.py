@@ -21,6 +21,11 @@ def _gelu(x):
     (64, 1024, 3072, 1, 4, False, False),    # split-K slabs
     (200, 320, 512, 2, 1, False, True),      # 128x64 tile
     (1, 151936, 256, 0, 1, False, False),    # LM-head shape, one row
+    (256, 256, 64, 3, 1, False, False),      # 256x256 tile: a single K tile
+    (600, 520, 4192, 3, 1, True, True),      # ragged M and N, odd number of K tiles, K tail of 32
+    (1000, 768, 128, 3, 1, False, True),
+    (300, 1024, 1984, 3, 3, False, False),   # split-K slabs, uneven split
+    (2100, 2304, 2048, 3, 1, False, False),  # more tiles than the XCD grouping width
 ])
 def test_gemm_matches_fp64(tiny_model, M, N, K, tile, ksplit, gelu, bias):
     m = tiny_model[0]
