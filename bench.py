@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--preset", default="1.7b")
-    ap.add_argument("--batch", type=int, default=512, help="30 s clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="30 s clips per GPU per step")
     ap.add_argument("--clip-seconds", type=float, default=30.0)
     ap.add_argument("--max-tokens", type=int, default=448)
     ap.add_argument("--no-stop-rules", action="store_true")

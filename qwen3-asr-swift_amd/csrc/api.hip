@@ -47,6 +47,7 @@ int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
     m->device = device;
     try {
         HIP_CHECK(hipStreamCreate(&m->stream));
+        HIP_CHECK(hipStreamCreate(&m->stream2));
         m->zero_page = m->dalloc<bf16_t>(512);
         HIP_CHECK(hipMemset(m->zero_page, 0, 1024));
         mel_tables_create(m->mel);
@@ -65,6 +66,8 @@ void q3asr_destroy(q3asr_model* m) {
     mel_tables_destroy(m->mel);
     m->arena.release();
     for (void* p : m->owned) (void)hipFree(p);
+    for (hipEvent_t e : m->chain_events) (void)hipEventDestroy(e);
+    if (m->stream2) (void)hipStreamDestroy(m->stream2);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

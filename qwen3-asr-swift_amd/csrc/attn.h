@@ -34,6 +34,7 @@ struct DecodeAttnParams {
     bf16_t* O; int64_t o_ld;
     int B, kv_heads, group;
     float scale;
+    int max_blocks = 0;                     // > 0: at most this many workgroups, each looping over (utterance, head) items
 };
 // work: algorithmic K/V bytes of the launch (profiling only)
 void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, double work = 0);

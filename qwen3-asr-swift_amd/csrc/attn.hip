@@ -160,7 +160,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     __shared__ float sm_m[4][GROUP], sm_l[4][GROUP];
     __shared__ float so[4][GROUP][D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int u = blockIdx.x, kvh = blockIdx.y;
+    // (utterance, kv head) work items, strided over the grid: the launcher may cap the grid so that a fixed
+    // number of workgroups per CU stream the cache while another stream's kernels share the CUs
+    const int items = p.B * p.kv_heads;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int u = item % p.B, kvh = item / p.B;
     const int len = p.lens[u] + p.len_add;
     const bf16_t* Kb = p.K + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
     const bf16_t* Vb = p.V + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
@@ -268,6 +272,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
         }
         p.O[(int64_t)u * p.o_ld + (kvh * GROUP + q) * D + d] = f32_to_bf16(O / L);
     }
+    __syncthreads();  // the merge buffers are reused by the next item
+    }
 }
 
 }  // namespace
@@ -278,7 +284,7 @@ void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s, double
     Q3_REQUIRE(p.q_ld % 8 == 0 && p.kv_ld % 8 == 0 && p.kv_hs % 8 == 0 && p.o_ld % 4 == 0, "flash attention: misaligned strides");
     dim3 grid(p.n_tiles, p.heads), block(256);
     ProfScope ps(head_dim == 64 ? (p.causal ? "flash_kernel<64,true>" : "flash_kernel<64,false>")
-                                : (p.causal ? "flash_kernel<128,true>" : "flash_kernel<128,false>"), work);
+                                : (p.causal ? "flash_kernel<128,true>" : "flash_kernel<128,false>"), work, s);
     if (head_dim == 64) {
         if (p.causal) hipLaunchKernelGGL((flash_kernel<64, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_kernel<64, false>), grid, block, 0, s, p);
@@ -292,8 +298,9 @@ void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s, double
 void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, double work) {
     if (p.B <= 0) return;
     Q3_REQUIRE(head_dim == 128, "decode attention: head_dim must be 128");
-    dim3 grid(p.B, p.kv_heads), block(256);
-    ProfScope ps("decode_attn_kernel", work);
+    const int items = p.B * p.kv_heads;
+    dim3 grid(p.max_blocks > 0 ? std::min(items, p.max_blocks) : items), block(256);
+    ProfScope ps("decode_attn_kernel", work, s);
     switch (p.group) {
         case 1: hipLaunchKernelGGL((decode_attn_kernel<1>), grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL((decode_attn_kernel<2>), grid, block, 0, s, p); break;

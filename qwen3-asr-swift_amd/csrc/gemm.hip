@@ -23,7 +23,7 @@ namespace {
 // LDS ring depth: the 128x128 tile keeps two 32 KB stages (two workgroups per CU); the smaller
 // tiles, used when few rows meet wide weights (decode), keep four so that three tiles of weights
 // are in flight per workgroup.
-constexpr int gemm_stages(int mt, int nt) { return (mt == 4 && nt == 4) ? 2 : 4; }
+constexpr int gemm_stages(int mt, int nt) { return (mt == 4 && nt == 4) ? 2 : (mt == 2 && nt == 2) ? 4 : 3; }
 
 struct ConvRow {
     int64_t base;
@@ -187,19 +187,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             __builtin_amdgcn_s_barrier();
             if (t + STAGES - 1 < nt) stage((t + STAGES - 1) % STAGES, kt0 + t + STAGES - 1);
             const char* sb = smem + (t % STAGES) * STAGE;
+            // All fragment reads of the K tile are issued before its first MFMA (pinned: left alone, the
+            // scheduler alternates small read groups with MFMAs behind full lgkmcnt waits, and a workgroup
+            // with one wave per SIMD then sits through the LDS latency several times per tile).
+            bf16x8 wf[2][NT], af[2][MT];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 wf[NT], af[MT];
 #pragma unroll
-                for (int b = 0; b < NT; ++b) wf[b] = *(const bf16x8*)(sb + w_rd[ks] + b * 4 * 128);
+                for (int b = 0; b < NT; ++b) wf[ks][b] = *(const bf16x8*)(sb + w_rd[ks] + b * 4 * 128);
 #pragma unroll
-                for (int a = 0; a < MT; ++a) af[a] = *(const bf16x8*)(sb + a_rd[ks] + a * 16 * 128);
+                for (int a = 0; a < MT; ++a) af[ks][a] = *(const bf16x8*)(sb + a_rd[ks] + a * 16 * 128);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
                     for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], af[a], acc[a][b], 0, 0, 0);
-            }
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][b], af[ks][a], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -310,7 +317,7 @@ void launch_t(const GemmParams& p, hipStream_t s) {
     static char name[64];
     if (!name[0]) snprintf(name, sizeof name, "gemm_kernel<%d,%d,%d,%d,%d>", MT, NT, AMODE, OUT, WFMT);
     {
-        ProfScope ps(name, 2.0 * p.M * p.N * p.K);
+        ProfScope ps(name, 2.0 * p.M * p.N * p.K, s);
         hipLaunchKernelGGL((gemm_kernel<MT, NT, AMODE, OUT, WFMT>), dim3(tiles, 1, p.ksplit), dim3(256), lds, s, p);
     }
     HIP_CHECK(hipGetLastError());

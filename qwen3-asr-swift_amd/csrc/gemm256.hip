@@ -289,7 +289,7 @@ void launch_o(const GemmParams& p, hipStream_t s) {
     static char name[64];
     if (!name[0]) snprintf(name, sizeof name, "gemm256_kernel<%d>", OUT);
     {
-        ProfScope ps(name, 2.0 * p.M * p.N * p.K);
+        ProfScope ps(name, 2.0 * p.M * p.N * p.K, s);
         hipLaunchKernelGGL((gemm256_kernel<OUT>), dim3(tiles, 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
     }
     HIP_CHECK(hipGetLastError());

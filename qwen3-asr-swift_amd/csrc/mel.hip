@@ -261,7 +261,7 @@ void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, d
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
                 const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work) {
     if (n_tiles <= 0) return;
-    ProfScope ps("mel_kernel", work);
+    ProfScope ps("mel_kernel", work, s);
     hipLaunchKernelGGL(mel_kernel, dim3(n_tiles), dim3(256), 0, s, audio, d_off, d_len, d_tile_utt, d_tile_f0, t.hann,
                        t.twid, t.fb_lo, t.fb_cnt, t.fb_off, t.fb_w, out, t_stride, d_max);
     HIP_CHECK(hipGetLastError());

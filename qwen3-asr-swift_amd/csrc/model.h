@@ -114,8 +114,11 @@ struct q3asr_model {
     // decode-step GEMM variants (tile, split-K) per projection, measured once per batch size
     struct DecodePlan {
         int tile[4], ks[4];  // qkv, o, gate_up, down
+        int fused[4];        // 1: unsplit, with the consumer's work in the GEMM epilogue instead of partial-sum slabs
     };
     std::map<int, DecodePlan> decode_plans;
+    hipStream_t stream2 = nullptr;           // second decode stream (the two halves of a large group)
+    std::vector<hipEvent_t> chain_events;    // ordering events between the two decode streams
 
     template <class T>
     T* dalloc(size_t count) {

@@ -348,28 +348,36 @@ q3asr_model::DecodePlan decode_plan(Ctx& c, int b, GemmWFmt wf) {
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
     constexpr int REPS = 8;
+    // epilogue of the unsplit, fused form of each projection: bf16 q/k/v rows, residual add, SwiGLU, residual add
+    const GemmOut fused_out[4] = {OUT_BF16, OUT_F32_ACC, OUT_SWIGLU, OUT_F32_ACC};
+    const bool allow_fused = !getenv("Q3ASR_DECODE_NO_FUSE");
     for (int g = 0; g < 4; ++g) {
         plan.tile[g] = b > 64 ? 2 : 1;
         plan.ks[g] = 1;
+        plan.fused[g] = 0;
         double best = 1e30;
         for (int tile : {1, 2, 0, 3}) {
             if ((tile == 3 && (wf != W_BF16 || b <= 128)) || (tile == 1 && b > 128)) continue;
             if (env_tile && atoi(env_tile) != tile) continue;
-            for (int ks : {1, 2, 4, 8}) {
+            for (int ks : {0, 1, 2, 4, 8}) {  // 0: the fused form
                 if (ks > 1 && ks * 4 > W[g]->K / 64) continue;  // at least four K tiles per split
                 if (env_split && atoi(env_split) != ks) continue;
+                if (ks == 0 && (!allow_fused || (g == 2 && tile == 1))) continue;  // no SwiGLU epilogue on the 64x64 tile
                 GemmParams p = gp(c, A, W[g]->K, *W[g], b);
-                p.out = slab; p.ldo = W[g]->N; p.ksplit = ks; p.slab_stride = (int64_t)b * W[g]->N;
-                for (int i = 0; i < 2; ++i) launch_gemm(p, A_PLAIN, OUT_SLAB, wf, tile, c.s);
+                p.out = slab; p.ldo = g == 2 && ks == 0 ? W[g]->N / 2 : W[g]->N;
+                p.ksplit = std::max(ks, 1); p.slab_stride = (int64_t)b * W[g]->N;
+                const GemmOut out = ks == 0 ? fused_out[g] : OUT_SLAB;
+                for (int i = 0; i < 2; ++i) launch_gemm(p, A_PLAIN, out, wf, tile, c.s);
                 HIP_CHECK(hipEventRecord(e0, c.s));
-                for (int i = 0; i < REPS; ++i) launch_gemm(p, A_PLAIN, OUT_SLAB, wf, tile, c.s);
+                for (int i = 0; i < REPS; ++i) launch_gemm(p, A_PLAIN, out, wf, tile, c.s);
                 HIP_CHECK(hipEventRecord(e1, c.s));
                 HIP_CHECK(hipEventSynchronize(e1));
                 float ms = 0;
                 HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                const double slab_us = 2.0 * ks * b * (double)W[g]->N * 4.0 / 3.0e6;  // at ~3 TB/s
-                const double us = ms * 1000.0 / REPS + slab_us;
-                if (us < best) { best = us; plan.tile[g] = tile; plan.ks[g] = ks; }
+                // a split's consumer reads the slabs back (~3 TB/s); gate/up partials also need the reduce kernel
+                const double extra_us = ks == 0 ? 0.0 : ks * b * (double)W[g]->N * 4.0 / 3.0e6 + (g == 2 ? 4.0 : 0.0);
+                const double us = ms * 1000.0 / REPS + extra_us;
+                if (us < best) { best = us; plan.tile[g] = tile; plan.ks[g] = std::max(ks, 1); plan.fused[g] = ks == 0; }
             }
         }
     }
@@ -377,8 +385,9 @@ q3asr_model::DecodePlan decode_plan(Ctx& c, int b, GemmWFmt wf) {
     (void)hipEventDestroy(e1);
     m->arena.restore(mark);
     if (getenv("Q3ASR_VERBOSE"))
-        fprintf(stderr, "q3asr: decode plan for %d rows (tile/split): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n", b, plan.tile[0],
-                plan.ks[0], plan.tile[1], plan.ks[1], plan.tile[2], plan.ks[2], plan.tile[3], plan.ks[3]);
+        fprintf(stderr, "q3asr: decode plan for %d rows (tile/split, split 0 = fused epilogue): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n",
+                b, plan.tile[0], plan.fused[0] ? 0 : plan.ks[0], plan.tile[1], plan.fused[1] ? 0 : plan.ks[1], plan.tile[2],
+                plan.fused[2] ? 0 : plan.ks[2], plan.tile[3], plan.fused[3] ? 0 : plan.ks[3]);
     m->decode_plans[b] = plan;
     return plan;
 }
@@ -485,11 +494,14 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         for (int i = 0; i < b; ++i) memcpy(&f[(size_t)i * max_tokens], req->forced_tokens + (size_t)idx[i] * max_tokens, (size_t)max_tokens * 4);
         d_forced = c.up(f);
     }
-    int head_tile = gemm_pick_tile(b, cfg.vocab);  // 256x256 once the batch fills more than half of its rows
-    if (head_tile == 1 || (head_tile == 3 && (wf != W_BF16 || (b <= 128 && !getenv("Q3ASR_FORCE_TILE"))))) head_tile = 0;
-    const int nparts = gemm_argmax_parts(cfg.vocab, head_tile);
-    float* part_val = c.get<float>((size_t)b * nparts);
-    int* part_idx = c.get<int>((size_t)b * nparts);
+    auto head_tile_for = [&](int rows) {  // 256x256 once the rows fill more than half of the tile
+        int t = gemm_pick_tile(rows, cfg.vocab);
+        if (t == 1 || (t == 3 && (wf != W_BF16 || (rows <= 128 && !getenv("Q3ASR_FORCE_TILE"))))) t = 0;
+        return t;
+    };
+    const int max_parts = gemm_argmax_parts(cfg.vocab, 1);  // the narrowest tile writes the most partials
+    float* part_val = c.get<float>((size_t)b * max_parts);
+    int* part_idx = c.get<int>((size_t)b * max_parts);
     bf16_t* x_last = c.get<bf16_t>((size_t)b * H);
     float* logits = req->tap_logits && req->tap_steps > 0 ? c.get<float>((size_t)b * cfg.vocab) : nullptr;
 
@@ -513,26 +525,31 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
     const int half = std::min(cfg.rotary_dim, hd) / 2;
 
     // LM head on `rows` normalised rows -> st_argmax (and optional logits tap)
-    auto lm_head = [&](const bf16_t* x, int rows, int step) {
+    // (utterances r0 .. r0 + rows - 1 of the group, on stream s)
+    auto lm_head = [&](const bf16_t* x, int r0, int rows, int step, hipStream_t s) {
         const bool tap = logits && step < req->tap_steps;
+        const int head_tile = head_tile_for(rows);
         GemmParams p = gp(c, x, H, m->embed, rows);
         if (tap) {
-            p.out = logits; p.ldo = cfg.vocab;
-            launch_gemm(p, A_PLAIN, OUT_F32, wf, head_tile, c.s);
-            launch_argmax_rows(logits, rows, cfg.vocab, st_argmax, c.s);
+            float* lg = logits + (size_t)r0 * cfg.vocab;
+            p.out = lg; p.ldo = cfg.vocab;
+            launch_gemm(p, A_PLAIN, OUT_F32, wf, head_tile, s);
+            launch_argmax_rows(lg, rows, cfg.vocab, st_argmax + r0, s);
             for (int i = 0; i < rows; ++i)
-                HIP_CHECK(hipMemcpyAsync(req->tap_logits + ((size_t)idx[i] * req->tap_steps + step) * cfg.vocab,
-                                         logits + (size_t)i * cfg.vocab, (size_t)cfg.vocab * 4, hipMemcpyDeviceToHost, c.s));
+                HIP_CHECK(hipMemcpyAsync(req->tap_logits + ((size_t)idx[r0 + i] * req->tap_steps + step) * cfg.vocab,
+                                         lg + (size_t)i * cfg.vocab, (size_t)cfg.vocab * 4, hipMemcpyDeviceToHost, s));
         } else {
-            p.part_val = part_val; p.part_idx = part_idx; p.nparts = nparts;
-            launch_gemm(p, A_PLAIN, OUT_ARGMAX, wf, head_tile, c.s);
-            launch_argmax_reduce(part_val, part_idx, nparts, rows, st_argmax, c.s);
+            const int nparts = gemm_argmax_parts(cfg.vocab, head_tile);
+            p.part_val = part_val + (size_t)r0 * max_parts; p.part_idx = part_idx + (size_t)r0 * max_parts; p.nparts = nparts;
+            launch_gemm(p, A_PLAIN, OUT_ARGMAX, wf, head_tile, s);
+            launch_argmax_reduce(p.part_val, p.part_idx, nparts, rows, st_argmax + r0, s);
         }
     };
-    auto step = [&](int advance) {
-        StepParams sp2{st_argmax, st_tokens, st_ntok, st_done, st_seen, st_next, st_len, st_active, d_forced, b, max_tokens, advance,
+    auto step = [&](int advance, int r0, int rows, int* active, hipStream_t s) {
+        StepParams sp2{st_argmax + r0, st_tokens + (size_t)r0 * max_tokens, st_ntok + r0, st_done + r0, st_seen + r0, st_next + r0,
+                       st_len + r0, active, d_forced ? d_forced + (size_t)r0 * max_tokens : nullptr, rows, max_tokens, advance,
                        req->forced_tokens ? 0 : req->stop_rules};
-        launch_step(sp2, c.s);
+        launch_step(sp2, s);
     };
 
     // ---- prefill (QuantizedTextDecoder.swift:384-446 over the packed prompts) ----
@@ -585,71 +602,146 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             }
         }
         launch_rmsnorm(hid, m->final_norm, x_last, b, H, cfg.rms_eps, d_last, nullptr, 0, 0, c.s);  // :386, last position only
-        lm_head(x_last, b, 0);
-        step(0);
+        lm_head(x_last, 0, b, 0, c.s);
+        step(0, 0, b, st_active, c.s);
         m->arena.restore(mark);
     }
     HIP_CHECK(hipEventRecord(ev.e[3], c.s));
 
     // ---- greedy decode (Qwen3ASR.swift:567-632) ----
     {
-        float* hd_ = c.get<float>((size_t)b * H);
-        bf16_t* xn = c.get<bf16_t>((size_t)b * H);
-        bf16_t* qd = c.get<bf16_t>((size_t)b * nh * hd);
-        bf16_t* att = c.get<bf16_t>((size_t)b * nh * hd);
-        bf16_t* act = c.get<bf16_t>((size_t)b * cfg.inter);
-        // Few rows, wide weights: every projection may be split along K so that enough workgroups
-        // stream the weights; the partial sums are reduced by whichever kernel consumes them next.
-        // The (tile, split) pair of each projection is measured once per batch size.
-        const q3asr_model::DecodePlan plan = decode_plan(c, b, wf);
-        const int ks_qkv = plan.ks[0], ks_o = plan.ks[1], ks_gu = plan.ks[2], ks_dn = plan.ks[3];
-        size_t slab_elems = (size_t)ks_qkv * b * QKV;
-        slab_elems = std::max(slab_elems, (size_t)ks_o * b * H);
-        slab_elems = std::max(slab_elems, (size_t)ks_gu * b * 2 * cfg.inter);
-        slab_elems = std::max(slab_elems, (size_t)ks_dn * b * H);
-        float* slab = c.get<float>(slab_elems);
-        auto slab_gemm = [&](const bf16_t* A, int64_t lda, const LinearW& W, int which) {
-            GemmParams p = gp(c, A, lda, W, b);
-            p.out = slab; p.ldo = W.N; p.ksplit = plan.ks[which]; p.slab_stride = (int64_t)b * W.N;
-            launch_gemm(p, A_PLAIN, OUT_SLAB, wf, plan.tile[which], c.s);
+        // The step's attention streams the KV cache (HBM-bound) while its projections are MFMA-bound,
+        // so a large group is decoded as two halves on two streams, chained by events so that the
+        // attention kernels of the halves alternate and each half's projections run beside the other
+        // half's attention.  Q3ASR_DECODE_STREAMS=1 keeps one stream.
+        const char* env_streams = getenv("Q3ASR_DECODE_STREAMS");
+        const int n_half = (env_streams ? atoi(env_streams) >= 2 : b >= 768) && b >= 2 ? 2 : 1;
+        // With two streams the attention grid is capped (workgroups loop over their items) so that the
+        // other half's projection kernels always find free registers and LDS on every CU.
+        const char* env_blocks = getenv("Q3ASR_ATTN_BLOCKS");
+        const int attn_blocks = env_blocks ? atoi(env_blocks) : 0;
+        struct Half {
+            int r0, n;
+            hipStream_t s;
+            float* hid; bf16_t *xn, *qkvb, *qd, *att, *act, *x_last; float* slab;
+            int* active_dev;
+            q3asr_model::DecodePlan plan;
+        } hv[2];
+        for (int h = 0; h < n_half; ++h) {
+            Half& x = hv[h];
+            x.r0 = h ? hv[0].n : 0;
+            x.n = n_half == 1 ? b : (h ? b - hv[0].n : (b + 1) / 2);
+            x.s = h ? m->stream2 : c.s;
+            x.hid = c.get<float>((size_t)x.n * H);
+            x.xn = c.get<bf16_t>((size_t)x.n * H);
+            x.qd = c.get<bf16_t>((size_t)x.n * nh * hd);
+            x.qkvb = c.get<bf16_t>((size_t)x.n * QKV);
+            x.att = c.get<bf16_t>((size_t)x.n * nh * hd);
+            x.act = c.get<bf16_t>((size_t)x.n * cfg.inter);
+            x.x_last = x_last + (size_t)x.r0 * H;
+            x.active_dev = st_active + h;
+            // Few rows, wide weights: every projection may be split along K so that enough workgroups
+            // stream the weights; the partial sums are reduced by whichever kernel consumes them next.
+            // The (tile, split) pair of each projection is measured once per row count.
+            x.plan = decode_plan(c, x.n, wf);
+            size_t slab_elems = (size_t)x.plan.ks[0] * x.n * QKV;
+            slab_elems = std::max(slab_elems, (size_t)x.plan.ks[1] * x.n * H);
+            slab_elems = std::max(slab_elems, (size_t)x.plan.ks[2] * x.n * 2 * cfg.inter);
+            slab_elems = std::max(slab_elems, (size_t)x.plan.ks[3] * x.n * H);
+            x.slab = c.get<float>(slab_elems);
+        }
+        // One projection: split-K partial sums into the slab, or (fused plan) unsplit with the consumer's
+        // work in the epilogue, writing `fused_dst` with row stride `fused_ld`.  Returns the number of slabs
+        // the consumer still has to reduce (0 when fused).
+        auto proj = [&](const Half& x, const bf16_t* A, int64_t lda, const LinearW& W, int which, GemmOut fused_kind, void* fused_dst,
+                        int64_t fused_ld) {
+            GemmParams p = gp(c, A, lda, W, x.n);
+            if (x.plan.fused[which]) {
+                p.out = fused_dst; p.ldo = fused_ld;
+                launch_gemm(p, A_PLAIN, fused_kind, wf, x.plan.tile[which], x.s);
+                return 0;
+            }
+            p.out = x.slab; p.ldo = W.N; p.ksplit = x.plan.ks[which]; p.slab_stride = (int64_t)x.n * W.N;
+            launch_gemm(p, A_PLAIN, OUT_SLAB, wf, x.plan.tile[which], x.s);
+            return x.plan.ks[which];
         };
+        // per-layer "attention issued" events of each half
+        if ((int)m->chain_events.size() < 2 * cfg.layers + 2) {
+            const size_t old = m->chain_events.size();
+            m->chain_events.resize(2 * cfg.layers + 2);
+            for (size_t i = old; i < m->chain_events.size(); ++i) HIP_CHECK(hipEventCreateWithFlags(&m->chain_events[i], hipEventDisableTiming));
+        }
+        hipEvent_t* ev_attn[2] = {m->chain_events.data(), m->chain_events.data() + cfg.layers};
+        hipEvent_t ev_fork = m->chain_events[2 * cfg.layers], ev_join = m->chain_events[2 * cfg.layers + 1];
         int active = b;
         HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
         HIP_CHECK(hipStreamSynchronize(c.s));
+        if (n_half == 2) {  // the second stream starts after everything queued so far
+            HIP_CHECK(hipEventRecord(ev_fork, c.s));
+            HIP_CHECK(hipStreamWaitEvent(m->stream2, ev_fork, 0));
+        }
+        int pend_down[2] = {0, 0};  // slabs the last down-projection of each half left to reduce
         for (int it = 1; it < max_tokens && active > 0; ++it) {
-            // K and V rows visible this step (counted as if no utterance has stopped yet)
-            double kv_bytes = 0;
-            for (int i = 0; i < b; ++i) kv_bytes += 2.0 * 2.0 * nkv * hd * (double)(utt_rows[i] + it);
-            launch_embed_tokens(st_next, b, H, qemb ? nullptr : (const bf16_t*)m->embed.w, qemb ? (const uint32_t*)m->embed.w : nullptr,
-                                m->embed.scales, m->embed.biases, cfg.group_size, hd_, c.s);
+            for (int h = 0; h < n_half; ++h)
+                launch_embed_tokens(st_next + hv[h].r0, hv[h].n, H, qemb ? nullptr : (const bf16_t*)m->embed.w,
+                                    qemb ? (const uint32_t*)m->embed.w : nullptr, m->embed.scales, m->embed.biases, cfg.group_size,
+                                    hv[h].hid, hv[h].s);
             for (int l = 0; l < cfg.layers; ++l) {
                 const DecLayerW& L = m->dec[l];
-                // residual += previous layer's down-projection partials, then input norm
-                launch_rmsnorm(hd_, L.in_norm, xn, b, H, cfg.rms_eps, nullptr, slab, l ? ks_dn : 0, (int64_t)b * H, c.s);
-                slab_gemm(xn, H, L.qkv, 0);
-                RopeParams rp{nullptr, QKV, slab, ks_qkv, (int64_t)b * QKV, qd, (int64_t)nh * hd, b, nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps,
-                              m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos, nullptr, nullptr, st_len,
-                              kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
-                launch_rope(rp, c.s);
-                DecodeAttnParams dp{qd, (int64_t)nh * hd, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride, st_len, 1, att,
-                                    (int64_t)nh * hd, b, nkv, nh / nkv, scale};
-                launch_decode_attn(dp, hd, c.s, kv_bytes);
-                slab_gemm(att, (int64_t)nh * hd, L.o, 1);
-                launch_rmsnorm(hd_, L.post_norm, xn, b, H, cfg.rms_eps, nullptr, slab, ks_o, (int64_t)b * H, c.s);
-                // (a SwiGLU epilogue on the 64x128 tile measured slower here than partials + this reduce:
-                // four row tiles re-read the 50 MB gate/up weights)
-                slab_gemm(xn, H, L.gate_up, 2);
-                launch_swiglu_reduce(slab, ks_gu, (int64_t)b * 2 * cfg.inter, b, 2 * cfg.inter, act, c.s);
-                slab_gemm(act, cfg.inter, L.down, 3);
+                bf16_t* kl = kc + l * layer_stride;
+                bf16_t* vl = vc + l * layer_stride;
+                for (int h = 0; h < n_half; ++h) {
+                    const Half& x = hv[h];
+                    // residual += previous layer's down-projection partials (if it left any), then input norm
+                    launch_rmsnorm(x.hid, L.in_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.n * H, x.s);
+                    const int ns = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
+                    RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.n * QKV, x.qd, (int64_t)nh * hd, x.n, nh,
+                                  nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos,
+                                  nullptr, nullptr, st_len + x.r0, kl + x.r0 * utt_stride, vl + x.r0 * utt_stride, utt_stride, head_stride};
+                    launch_rope(rp, x.s);
+                }
+                for (int h = 0; h < n_half; ++h) {
+                    const Half& x = hv[h];
+                    if (n_half == 2) {
+                        // half 0 follows half 1's attention of the previous layer, half 1 follows half 0's of this layer
+                        const int dep_l = h ? l : (l ? l - 1 : cfg.layers - 1);
+                        if (h || l || it > 1) HIP_CHECK(hipStreamWaitEvent(x.s, ev_attn[h ^ 1][dep_l], 0));
+                    }
+                    // K and V rows visible this step (counted as if no utterance has stopped yet)
+                    double kv_bytes = 0;
+                    for (int i = 0; i < x.n; ++i) kv_bytes += 2.0 * 2.0 * nkv * hd * (double)(utt_rows[x.r0 + i] + it);
+                    DecodeAttnParams dp{x.qd, (int64_t)nh * hd, kl + x.r0 * utt_stride, vl + x.r0 * utt_stride, utt_stride, head_stride,
+                                        st_len + x.r0, 1, x.att, (int64_t)nh * hd, x.n, nkv, nh / nkv, scale};
+                    dp.max_blocks = attn_blocks;
+                    launch_decode_attn(dp, hd, x.s, kv_bytes);
+                    if (n_half == 2) HIP_CHECK(hipEventRecord(ev_attn[h][l], x.s));
+                }
+                for (int h = 0; h < n_half; ++h) {
+                    const Half& x = hv[h];
+                    const int ns_o = proj(x, x.att, (int64_t)nh * hd, L.o, 1, OUT_F32_ACC, x.hid, H);
+                    launch_rmsnorm(x.hid, L.post_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, ns_o, (int64_t)x.n * H, x.s);
+                    const int ns_gu = proj(x, x.xn, H, L.gate_up, 2, OUT_SWIGLU, x.act, cfg.inter);
+                    if (ns_gu) launch_swiglu_reduce(x.slab, ns_gu, (int64_t)x.n * 2 * cfg.inter, x.n, 2 * cfg.inter, x.act, x.s);
+                    pend_down[h] = proj(x, x.act, cfg.inter, L.down, 3, OUT_F32_ACC, x.hid, H);
+                }
             }
-            launch_rmsnorm(hd_, m->final_norm, x_last, b, H, cfg.rms_eps, nullptr, slab, ks_dn, (int64_t)b * H, c.s);
-            lm_head(x_last, b, it);
-            step(1);
+            for (int h = 0; h < n_half; ++h) {
+                const Half& x = hv[h];
+                launch_rmsnorm(x.hid, m->final_norm, x.x_last, x.n, H, cfg.rms_eps, nullptr, x.slab, pend_down[h], (int64_t)x.n * H, x.s);
+                lm_head(x.x_last, x.r0, x.n, it, x.s);
+                step(1, x.r0, x.n, x.active_dev, x.s);
+            }
             res->decode_steps += 1;
             if (it % POLL_STEPS == 0 || it + 1 == max_tokens) {
-                HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
-                HIP_CHECK(hipStreamSynchronize(c.s));
+                int act_h[2] = {0, 0};
+                for (int h = 0; h < n_half; ++h) HIP_CHECK(hipMemcpyAsync(&act_h[h], hv[h].active_dev, 4, hipMemcpyDeviceToHost, hv[h].s));
+                for (int h = 0; h < n_half; ++h) HIP_CHECK(hipStreamSynchronize(hv[h].s));
+                active = act_h[0] + act_h[1];
             }
+        }
+        if (n_half == 2) {  // everything after the loop runs on the main stream
+            HIP_CHECK(hipEventRecord(ev_join, m->stream2));
+            HIP_CHECK(hipStreamWaitEvent(c.s, ev_join, 0));
         }
     }
     HIP_CHECK(hipEventRecord(ev.e[4], c.s));

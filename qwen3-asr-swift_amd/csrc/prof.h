@@ -9,11 +9,13 @@ void prof_start(hipStream_t s, int stride);
 // {"name", "launches", "timed", "ms_timed", "work", "work_timed"} objects.
 std::string prof_stop();
 bool prof_active();
-int prof_begin(const char* name, double work);  // slot (>= 0) when this launch is timed, -1 otherwise
-void prof_end(int slot);
+// slot (>= 0) when this launch is timed, -1 otherwise; the events go onto the stream the kernel is launched on
+int prof_begin(const char* name, double work, hipStream_t s);
+void prof_end(int slot, hipStream_t s);
 
 struct ProfScope {
     int slot;
-    ProfScope(const char* name, double work) : slot(prof_active() ? prof_begin(name, work) : -1) {}
-    ~ProfScope() { if (slot >= 0) prof_end(slot); }
+    hipStream_t s;
+    ProfScope(const char* name, double work, hipStream_t stream) : slot(prof_active() ? prof_begin(name, work, stream) : -1), s(stream) {}
+    ~ProfScope() { if (slot >= 0) prof_end(slot, s); }
 };

@@ -28,7 +28,7 @@ void prof_start(hipStream_t s, int stride) {
     g.used = 0;
 }
 
-int prof_begin(const char* name, double work) {
+int prof_begin(const char* name, double work, hipStream_t s) {
     Entry& e = g.entries[name];
     const bool timed = (e.launches % g.stride) == 0;
     e.launches += 1;
@@ -44,16 +44,16 @@ int prof_begin(const char* name, double work) {
     e.timed += 1;
     e.work_timed += work;
     e.slots.push_back(slot);
-    HIP_CHECK(hipEventRecord(g.ev[slot], g.s));
+    HIP_CHECK(hipEventRecord(g.ev[slot], s));
     return slot;
 }
 
-void prof_end(int slot) { HIP_CHECK(hipEventRecord(g.ev[slot + 1], g.s)); }
+void prof_end(int slot, hipStream_t s) { HIP_CHECK(hipEventRecord(g.ev[slot + 1], s)); }
 
 std::string prof_stop() {
     std::string out = "[";
     if (g.on) {
-        HIP_CHECK(hipStreamSynchronize(g.s));
+        HIP_CHECK(hipDeviceSynchronize());
         bool first = true;
         for (auto& kv : g.entries) {
             double ms = 0;

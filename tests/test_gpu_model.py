@@ -123,6 +123,23 @@ def test_batch_equals_single_and_order(tiny_model):
     assert abs(batch.audio_seconds - sum(len(a) for a in audios) / 16000.0) < 1e-6
 
 
+def test_two_stream_decode_equals_one_stream(tiny_model, monkeypatch):
+    """Large groups are decoded as two halves on two event-chained streams; a small group is forced through that
+    path here and must give the tokens (and stop points) of the single-stream loop."""
+    m, cfg, _ = tiny_model
+    audios = [synth.synth_audio(n, 80 + i) for i, n in enumerate((20000, 100000, 16000, 64000, 33333))]
+    monkeypatch.setenv("Q3ASR_DECODE_STREAMS", "1")
+    one = m.transcribe_batch(audios, 16000, max_tokens=24)
+    monkeypatch.setenv("Q3ASR_DECODE_STREAMS", "2")
+    two = m.transcribe_batch(audios, 16000, max_tokens=24)
+    assert one.tokens == two.tokens
+    forced = np.tile(np.arange(100, 110, dtype=np.int32), (5, 1))
+    a = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
+    monkeypatch.setenv("Q3ASR_DECODE_STREAMS", "1")
+    b = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
+    assert _rel(a.taps["logits"], b.taps["logits"]) <= 1e-3
+
+
 def test_greedy_free_running_matches_oracle_prefix(tiny_model):
     """Free-running greedy decode: identical ids up to the first step whose oracle margin is within tolerance."""
     m, cfg, ck = tiny_model
