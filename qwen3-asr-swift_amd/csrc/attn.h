@@ -26,6 +26,22 @@ struct FlashParams {
 // work: algorithmic FLOPs of the launch (profiling only)
 void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s, double work = 0);
 
+// Optional input of the decode-attention kernel: this step's raw q/k/v projections.  When given, the
+// kernel applies the per-head RMSNorm and RoPE itself (QuantizedTextDecoder.swift:148-169), appends the
+// new K and V rows to the cache at position lens[u], and attends over lens[u] cached keys plus the new one.
+struct DecodeRopeIn {
+    const bf16_t* qkv = nullptr;   // [B][ld] bf16 projections ((heads + 2 kv_heads) * 128 wide), or
+    const float* slab = nullptr;   // split-K partial sums [nslab][B][ld] of the same
+    int nslab = 0;
+    int64_t slab_stride = 0, ld = 0;
+    const float* q_norm_w = nullptr;
+    const float* k_norm_w = nullptr;
+    float eps = 0.f;
+    const float* cos_tab = nullptr;  // [max_pos][half]
+    const float* sin_tab = nullptr;
+    int half = 0, interleaved = 0, max_pos = 0;
+};
+
 struct DecodeAttnParams {
     const bf16_t* Q; int64_t q_ld;          // Q[u][head*D + d] (already normalised + rotated)
     const bf16_t* K; const bf16_t* V;       // cache[u*utt_stride + kvhead*head_stride + pos*D + d]
@@ -35,6 +51,7 @@ struct DecodeAttnParams {
     int B, kv_heads, group;
     float scale;
     int max_blocks = 0;                     // > 0: at most this many workgroups, each looping over (utterance, head) items
+    DecodeRopeIn rope;                      // set: Q is ignored, K/V are appended in place (len_add must be 0)
 };
 // work: algorithmic K/V bytes of the launch (profiling only)
 void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, double work = 0);

@@ -14,6 +14,8 @@
 // probabilities are broadcast with v_readlane, V rows are consumed coalesced by the VALU.
 #include "attn.h"
 #include "prof.h"
+#include "rope.h"
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -154,27 +156,23 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
 
 #undef FLASH_LOAD
 
-template <int GROUP>
+template <int GROUP, bool FUSED>
 __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     constexpr int D = 128;
     __shared__ float sm_m[4][GROUP], sm_l[4][GROUP];
     __shared__ float so[4][GROUP][D];
+    __shared__ __attribute__((aligned(16))) bf16_t sq[GROUP][D];  // FUSED: this step's normalised, rotated queries
+    __shared__ float snew[2][D];                                  // FUSED: the new key (rotated) and value, bf16-rounded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     // (utterance, kv head) work items, strided over the grid: the launcher may cap the grid so that a fixed
     // number of workgroups per CU stream the cache while another stream's kernels share the CUs
     const int items = p.B * p.kv_heads;
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int u = item % p.B, kvh = item / p.B;
-    const int len = p.lens[u] + p.len_add;
+    // FUSED: len counts the keys already cached; the new one is handled from LDS after the loop
+    const int len = p.lens[u] + (FUSED ? 0 : p.len_add);
     const bf16_t* Kb = p.K + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
     const bf16_t* Vb = p.V + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
-
-    Frag qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks].u = make_uint4(0, 0, 0, 0);
-        if (li < GROUP) qf[ks].u = *(const uint4*)(p.Q + (int64_t)u * p.q_ld + (kvh * GROUP + li) * D + 32 * ks + 8 * lg);
-    }
     const float sl2 = p.scale * 1.44269504088896340736f;
     float m = -INFINITY, l = 0.f;
     float o[GROUP][2];
@@ -235,7 +233,61 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     Frag kfA[4], kfB[4];
     uint32_t vvA[16], vvB[16];
     int t = wave;
-    if (t < ntiles) DA_LOAD(kfA, vvA, t);
+    if (t < ntiles) DA_LOAD(kfA, vvA, t);  // in flight while the queries are prepared
+    Frag qf[4];
+    if constexpr (FUSED) {
+        // One wave per head of this step's projections: GROUP query heads, then the key, then the value.
+        const DecodeRopeIn& r = p.rope;
+        const int heads = p.kv_heads * GROUP, pos = len;
+        const RopeTables tabs{r.cos_tab, r.sin_tab, r.half, r.interleaved, r.max_pos};
+        for (int sl = wave; sl < GROUP + 2; sl += 4) {
+            const int col = sl < GROUP ? (kvh * GROUP + sl) * D : (sl == GROUP ? (heads + kvh) * D : (heads + p.kv_heads + kvh) * D);
+            const int64_t src = (int64_t)u * r.ld + col + 2 * lane;
+            float x0, x1;
+            uint32_t raw;
+            if (r.slab) {
+                float2 acc = make_float2(0.f, 0.f);
+                for (int z = 0; z < r.nslab; ++z) {
+                    const float2 tt = *(const float2*)(r.slab + z * r.slab_stride + src);
+                    acc.x += tt.x;
+                    acc.y += tt.y;
+                }
+                x0 = acc.x; x1 = acc.y;
+                raw = pack_bf16x2(x0, x1);
+            } else {
+                raw = *(const uint32_t*)(r.qkv + src);
+                x0 = __uint_as_float(raw << 16);
+                x1 = __uint_as_float(raw & 0xffff0000u);
+            }
+            if (sl == GROUP + 1) {  // V: cached as is
+                *(uint32_t*)(const_cast<bf16_t*>(Vb) + (int64_t)pos * D + 2 * lane) = raw;
+                snew[1][2 * lane] = __uint_as_float(raw << 16);
+                snew[1][2 * lane + 1] = __uint_as_float(raw & 0xffff0000u);
+            } else {
+                const float2 y = rope_head(x0, x1, lane, sl < GROUP ? r.q_norm_w : r.k_norm_w, r.eps, tabs, pos);
+                const uint32_t packed = pack_bf16x2(y.x, y.y);
+                if (sl < GROUP) {
+                    *(uint32_t*)(&sq[sl][2 * lane]) = packed;
+                } else {
+                    *(uint32_t*)(const_cast<bf16_t*>(Kb) + (int64_t)pos * D + 2 * lane) = packed;
+                    snew[0][2 * lane] = __uint_as_float(packed << 16);
+                    snew[0][2 * lane + 1] = __uint_as_float(packed & 0xffff0000u);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks].u = make_uint4(0, 0, 0, 0);
+            if (li < GROUP) qf[ks].u = *(const uint4*)(&sq[li][32 * ks + 8 * lg]);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks].u = make_uint4(0, 0, 0, 0);
+            if (li < GROUP) qf[ks].u = *(const uint4*)(p.Q + (int64_t)u * p.q_ld + (kvh * GROUP + li) * D + 32 * ks + 8 * lg);
+        }
+    }
     while (t < ntiles) {
         const int t2 = t + 4;
         if (t2 < ntiles) DA_LOAD(kfB, vvB, t2);
@@ -248,6 +300,24 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     }
 #undef DA_LOAD
 #undef DA_COMPUTE
+    if constexpr (FUSED) {
+        if (wave == 0) {  // the new key and value, from LDS: one more online-softmax step per query head
+            const float k0 = snew[0][2 * lane], k1 = snew[0][2 * lane + 1], v0 = snew[1][2 * lane], v1 = snew[1][2 * lane + 1];
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q) {
+                const uint32_t qq = *(const uint32_t*)(&sq[q][2 * lane]);
+                const float sc = wave_sum(__uint_as_float(qq << 16) * k0 + __uint_as_float(qq & 0xffff0000u) * k1) * sl2;
+                const float mq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), q));
+                const float lq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l), q));
+                const float m_new = fmaxf(mq, sc);
+                const float alpha = mq == -INFINITY ? 0.f : exp2f(mq - m_new);
+                const float pr = exp2f(sc - m_new);
+                o[q][0] = fmaf(pr, v0, o[q][0] * alpha);
+                o[q][1] = fmaf(pr, v1, o[q][1] * alpha);
+                if (li == q) { m = m_new; l = lq * alpha + pr; }
+            }
+        }
+    }
     if (li < GROUP && lg == 0) {
         sm_m[wave][li] = m;
         sm_l[wave][li] = l;
@@ -301,10 +371,16 @@ void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, 
     const int items = p.B * p.kv_heads;
     dim3 grid(p.max_blocks > 0 ? std::min(items, p.max_blocks) : items), block(256);
     ProfScope ps("decode_attn_kernel", work, s);
-    switch (p.group) {
-        case 1: hipLaunchKernelGGL((decode_attn_kernel<1>), grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL((decode_attn_kernel<2>), grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL((decode_attn_kernel<4>), grid, block, 0, s, p); break;
+    const bool fused = p.rope.qkv || p.rope.slab;
+    if (fused) Q3_REQUIRE(p.len_add == 0 && p.rope.ld % 2 == 0 && p.rope.q_norm_w && p.rope.k_norm_w && p.rope.cos_tab && p.rope.sin_tab,
+                          "decode attention: incomplete fused q/k/v input");
+    switch (p.group * 2 + (fused ? 1 : 0)) {
+        case 2: hipLaunchKernelGGL((decode_attn_kernel<1, false>), grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((decode_attn_kernel<1, true>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((decode_attn_kernel<2, false>), grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((decode_attn_kernel<2, true>), grid, block, 0, s, p); break;
+        case 8: hipLaunchKernelGGL((decode_attn_kernel<4, false>), grid, block, 0, s, p); break;
+        case 9: hipLaunchKernelGGL((decode_attn_kernel<4, true>), grid, block, 0, s, p); break;
         default: throw Q3Error("decode attention: GQA group must be 1, 2 or 4");
     }
     HIP_CHECK(hipGetLastError());

@@ -1,5 +1,6 @@
 // Bandwidth-bound glue kernels of the transcription path (gfx950).
 #include "ops.h"
+#include "rope.h"
 
 namespace {
 
@@ -161,32 +162,9 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
         return;
     }
     const bool is_q = slot < p.heads;
-    const float* w = is_q ? p.q_norm_w : p.k_norm_w;
-    const float rstd = 1.0f / sqrtf(wave_sum(x0 * x0 + x1 * x1) / 128.0f + p.eps);
-    const float y0 = x0 * rstd * w[2 * lane], y1 = x1 * rstd * w[2 * lane + 1];
-    float r0 = y0, r1 = y1;
-    const int pp = min(pos, p.max_pos - 1);
-    const float* ct = p.cos_tab + (int64_t)pp * p.half;
-    const float* st = p.sin_tab + (int64_t)pp * p.half;
-    if (p.interleaved) {  // pairs (2i, 2i+1): QuantizedTextDecoder.swift:245-252
-        if (lane < p.half) {
-            const float c = ct[lane], s = st[lane];
-            r0 = y0 * c - y1 * s;
-            r1 = y1 * c + y0 * s;
-        }
-    } else {              // rotate-half, pairs (i, i + half): :253-259
-        const int e0 = 2 * lane, h2 = p.half >> 1, rot = 2 * p.half;
-        const int partner = (e0 < p.half) ? lane + h2 : lane - h2;
-        const float p0 = __shfl(y0, partner & 63, 64), p1 = __shfl(y1, partner & 63, 64);
-        if (e0 < p.half) {
-            r0 = y0 * ct[e0] - p0 * st[e0];
-            r1 = y1 * ct[e0 + 1] - p1 * st[e0 + 1];
-        } else if (e0 < rot) {
-            const int j = e0 - p.half;
-            r0 = y0 * ct[j] + p0 * st[j];
-            r1 = y1 * ct[j + 1] + p1 * st[j + 1];
-        }
-    }
+    const RopeTables tabs{p.cos_tab, p.sin_tab, p.half, p.interleaved, p.max_pos};
+    const float2 r = rope_head(x0, x1, lane, is_q ? p.q_norm_w : p.k_norm_w, p.eps, tabs, pos);
+    const float r0 = r.x, r1 = r.y;
     const uint32_t packed = pack_bf16x2(r0, r1);
     if (is_q) {
         *(uint32_t*)(p.q_out + (int64_t)row * p.q_ld + (int64_t)slot * 128 + 2 * lane) = packed;

@@ -613,9 +613,10 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         // The step's attention streams the KV cache (HBM-bound) while its projections are MFMA-bound,
         // so a large group is decoded as two halves on two streams, chained by events so that the
         // attention kernels of the halves alternate and each half's projections run beside the other
-        // half's attention.  Q3ASR_DECODE_STREAMS=1 keeps one stream.
+        // half's attention.  Opt-in (Q3ASR_DECODE_STREAMS=2): measured +3 % at 1024 clips, nothing at 512, and
+        // the co-running kernels stretch each other, which blurs per-kernel timings.
         const char* env_streams = getenv("Q3ASR_DECODE_STREAMS");
-        const int n_half = (env_streams ? atoi(env_streams) >= 2 : b >= 768) && b >= 2 ? 2 : 1;
+        const int n_half = env_streams && atoi(env_streams) >= 2 && b >= 2 ? 2 : 1;
         // With two streams the attention grid is capped (workgroups loop over their items) so that the
         // other half's projection kernels always find free registers and LDS on every CU.
         const char* env_blocks = getenv("Q3ASR_ATTN_BLOCKS");
@@ -681,6 +682,9 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             HIP_CHECK(hipStreamWaitEvent(m->stream2, ev_fork, 0));
         }
         int pend_down[2] = {0, 0};  // slabs the last down-projection of each half left to reduce
+        int qkv_slabs[2] = {0, 0};  // slabs of the current q/k/v projection (0: bf16 rows in qkvb)
+        const char* env_fuse = getenv("Q3ASR_FUSE_ROPE");
+        const bool fuse_rope = !(env_fuse && atoi(env_fuse) == 0) && nh / nkv <= 4 && (nh / nkv == 1 || nh / nkv == 2 || nh / nkv == 4);
         for (int it = 1; it < max_tokens && active > 0; ++it) {
             for (int h = 0; h < n_half; ++h)
                 launch_embed_tokens(st_next + hv[h].r0, hv[h].n, H, qemb ? nullptr : (const bf16_t*)m->embed.w,
@@ -694,11 +698,15 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                     const Half& x = hv[h];
                     // residual += previous layer's down-projection partials (if it left any), then input norm
                     launch_rmsnorm(x.hid, L.in_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.n * H, x.s);
-                    const int ns = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
-                    RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.n * QKV, x.qd, (int64_t)nh * hd, x.n, nh,
-                                  nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos,
-                                  nullptr, nullptr, st_len + x.r0, kl + x.r0 * utt_stride, vl + x.r0 * utt_stride, utt_stride, head_stride};
-                    launch_rope(rp, x.s);
+                    qkv_slabs[h] = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
+                    if (!fuse_rope) {
+                        const int ns = qkv_slabs[h];
+                        RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.n * QKV, x.qd, (int64_t)nh * hd, x.n,
+                                      nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
+                                      m->rope_max_pos, nullptr, nullptr, st_len + x.r0, kl + x.r0 * utt_stride, vl + x.r0 * utt_stride,
+                                      utt_stride, head_stride};
+                        launch_rope(rp, x.s);
+                    }
                 }
                 for (int h = 0; h < n_half; ++h) {
                     const Half& x = hv[h];
@@ -711,8 +719,13 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                     double kv_bytes = 0;
                     for (int i = 0; i < x.n; ++i) kv_bytes += 2.0 * 2.0 * nkv * hd * (double)(utt_rows[x.r0 + i] + it);
                     DecodeAttnParams dp{x.qd, (int64_t)nh * hd, kl + x.r0 * utt_stride, vl + x.r0 * utt_stride, utt_stride, head_stride,
-                                        st_len + x.r0, 1, x.att, (int64_t)nh * hd, x.n, nkv, nh / nkv, scale};
+                                        st_len + x.r0, fuse_rope ? 0 : 1, x.att, (int64_t)nh * hd, x.n, nkv, nh / nkv, scale};
                     dp.max_blocks = attn_blocks;
+                    if (fuse_rope) {  // q/k norm, RoPE and the cache append happen inside the attention kernel
+                        const int ns = qkv_slabs[h];
+                        dp.rope = DecodeRopeIn{ns ? nullptr : x.qkvb, ns ? x.slab : nullptr, ns, (int64_t)x.n * QKV, QKV, L.q_norm, L.k_norm,
+                                               cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos};
+                    }
                     launch_decode_attn(dp, hd, x.s, kv_bytes);
                     if (n_half == 2) HIP_CHECK(hipEventRecord(ev_attn[h][l], x.s));
                 }

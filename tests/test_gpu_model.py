@@ -140,6 +140,29 @@ def test_two_stream_decode_equals_one_stream(tiny_model, monkeypatch):
     assert _rel(a.taps["logits"], b.taps["logits"]) <= 1e-3
 
 
+@pytest.mark.parametrize("variant", ["default", "rotate_half"])
+def test_rope_inside_attention_equals_separate_kernel(variant, monkeypatch):
+    """Decode steps normalise / rotate q and k and append to the cache inside the attention kernel; the separate
+    kernel (the prefill's, Q3ASR_FUSE_ROPE=0) must give the same tokens and logits."""
+    cfg = make_config("tiny", **(dict(rope_interleaved=0) if variant == "rotate_half" else {}))
+    ck = synth.make_checkpoint(cfg, seed=11)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        audios = [synth.synth_audio(n, 90 + i) for i, n in enumerate((24000, 70000, 16000))]
+        forced = np.tile(np.arange(200, 212, dtype=np.int32), (3, 1))
+        fused = m.transcribe_batch(audios, 16000, max_tokens=12, forced_tokens=forced, tap_steps=12)
+        free_fused = m.transcribe_batch(audios, 16000, max_tokens=20)
+        monkeypatch.setenv("Q3ASR_FUSE_ROPE", "0")
+        plain = m.transcribe_batch(audios, 16000, max_tokens=12, forced_tokens=forced, tap_steps=12)
+        free_plain = m.transcribe_batch(audios, 16000, max_tokens=20)
+        # the new key's score is an fp32 VALU dot product in one path and an MFMA in the other; a flipped bf16
+        # rounding of an attention output moves a logit by ~1e-3 of the largest
+        assert _rel(fused.taps["logits"], plain.taps["logits"]) <= 5e-3
+        assert free_fused.tokens == free_plain.tokens
+    finally:
+        m.close()
+
+
 def test_greedy_free_running_matches_oracle_prefix(tiny_model):
     """Free-running greedy decode: identical ids up to the first step whose oracle margin is within tolerance."""
     m, cfg, ck = tiny_model
