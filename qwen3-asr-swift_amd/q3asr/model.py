@@ -178,6 +178,26 @@ class Qwen3ASRModel:
             return self.tokenizer.post_process(self.tokenizer.decode(toks))
         return " ".join(str(t) for t in toks)
 
+    def transcribe_long(self, audios, sample_rate=16000, mode="truncate", max_tokens=448, batch=None):
+        """Recordings of any length.  mode="truncate" is the reference's behaviour (everything after 30 s is
+        dropped, AudioPreprocessing.swift:307-316); "segment" / "segment_fixed" cut each recording into pieces of
+        at most 30 s (q3asr.segment), run all pieces as one sharded batch and join them per recording.
+        Returns (texts or joined id lists, per-recording list of piece token lists)."""
+        from .segment import join_tokens, segment_batch
+        pieces, owner = segment_batch(audios, sample_rate, mode)
+        step = batch or max(1, int(self.cfg.max_batch))
+        piece_tokens = []
+        for i in range(0, len(pieces), step):
+            piece_tokens += self.transcribe_batch(pieces[i:i + step], sample_rate, max_tokens=max_tokens).tokens
+        per_utt = [[] for _ in audios]
+        for toks, i in zip(piece_tokens, owner):
+            per_utt[i].append(toks)
+        if self.tokenizer is not None:
+            joined = [" ".join(t for t in (self.tokenizer.post_process(self.tokenizer.decode(p)) for p in ps) if t) for ps in per_utt]
+        else:
+            joined = join_tokens(piece_tokens, owner, len(audios))
+        return joined, per_utt
+
     def transcribe_batch(self, audios, sample_rate=16000, max_tokens=448, lang_ids=None, stop_rules=True, forced_tokens=None,
                          tap_steps=0, tap_embeds=False, device_audio=None):
         """audios: list of fp32 arrays (host).  device_audio: (device pointer, offsets int64[n+1]) of samples

@@ -163,6 +163,73 @@ def test_rope_inside_attention_equals_separate_kernel(variant, monkeypatch):
         m.close()
 
 
+@pytest.mark.parametrize("preset", ["0.6b", "1.7b"])
+def test_true_widths_two_layers(preset):
+    """The real layer widths (896 / 1024 encoder, 1024 / 2048 decoder, 14 / 16 encoder heads, 16 Q / 8 KV heads,
+    vocabulary 151 936) with two layers per stack, so that the CPU restatement finishes in seconds: catches tile-edge
+    and head-count assumptions the tiny configuration cannot."""
+    cfg = make_config(preset, enc_layers=2, layers=2)
+    ck = synth.make_checkpoint(cfg, seed=5)
+    audio = synth.synth_audio(16000 * 2 + 800, 31)
+    steps = 4
+    toks, ref_logits, stages = _oracle_run(cfg, ck, audio, steps)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        forced = np.zeros((1, steps), dtype=np.int32)
+        forced[0, :len(toks)] = toks
+        out = m.transcribe_batch([audio], 16000, max_tokens=steps, forced_tokens=forced, tap_steps=steps, tap_embeds=True)
+        n_a = int(out.n_audio_tokens[0])
+        assert n_a == stages["audio_embeds"].shape[0]
+        assert _rel(out.taps["audio_embeds"][:n_a], stages["audio_embeds"]) <= ENC_RTOL
+        assert _rel(out.taps["logits"][0, :len(toks)], ref_logits[:len(toks)]) <= LOGIT_RTOL
+    finally:
+        m.close()
+
+
+def test_forced_language_prefix_matches_oracle(tiny_model):
+    """Forced-language prompts (Qwen3ASR.swift:302-309): the prefix ids follow the assistant header, <asr_text> is
+    appended when missing, and the repetition rules are armed from the first token (:565-566)."""
+    m, cfg, ck = tiny_model
+    w = synth.checkpoint_to_f32(ck)
+    enc_cfg, dec_cfg = oracle_cfgs(cfg)
+    audio = synth.synth_audio(26000, 17)
+    for prefix in ([4128, 6364], [4128, 6364, 151704]):
+        trace = []
+        toks = oracle.generate.transcribe_tokens(audio, 16000, w, enc_cfg, dec_cfg, max_tokens=8, lang_ids=prefix, trace=trace)
+        ref = np.stack(trace)
+        forced = np.zeros((1, 8), dtype=np.int32)
+        forced[0, :len(toks)] = toks
+        out = m.transcribe_batch([audio], 16000, max_tokens=8, lang_ids=[prefix], forced_tokens=forced, tap_steps=8)
+        assert _rel(out.taps["logits"][0, :len(toks)], ref[:len(toks)]) <= LOGIT_RTOL
+    # a batch mixing forced and free utterances keeps them apart
+    mixed = m.transcribe_batch([audio, audio], 16000, max_tokens=6, lang_ids=[[4128, 6364], None], stop_rules=False)
+    alone = m.transcribe_batch([audio], 16000, max_tokens=6, stop_rules=False)
+    assert mixed.tokens[1] == alone.tokens[0]
+
+
+def test_long_audio_modes(tiny_model):
+    """A 33 s recording: "truncate" keeps the reference's behaviour (3000 frames -> 390 audio tokens, the clamp's
+    maximum taken over the whole recording, AudioPreprocessing.swift:269-316); "segment_fixed" runs 30 s + 3 s pieces
+    as independent utterances and joins them."""
+    m, cfg, ck = tiny_model
+    audio = synth.synth_audio(16000 * 33, 3)
+    w = synth.checkpoint_to_f32(ck)
+    enc_cfg, _ = oracle_cfgs(cfg)
+    out = m.transcribe_batch([audio], 16000, max_tokens=4, tap_embeds=True)
+    assert int(out.n_audio_tokens[0]) == 390
+    ref = oracle.encoder.encode(oracle.mel.process(audio, 16000), w, enc_cfg)
+    assert ref.shape[0] == 390 and _rel(out.taps["audio_embeds"][:390], ref) <= ENC_RTOL
+    joined, pieces = m.transcribe_long([audio], 16000, mode="truncate", max_tokens=4)
+    assert pieces[0] == [out.tokens[0]]
+    joined, pieces = m.transcribe_long([audio, audio[:16000 * 4]], 16000, mode="segment_fixed", max_tokens=4)
+    a = m.transcribe_batch([audio[:16000 * 30]], 16000, max_tokens=4).tokens[0]
+    b = m.transcribe_batch([audio[16000 * 30:]], 16000, max_tokens=4).tokens[0]
+    c = m.transcribe_batch([audio[:16000 * 4]], 16000, max_tokens=4).tokens[0]
+    assert pieces == [[a, b], [c]]
+    strip = lambda t: [x for x in t if x not in (151645, 151643)]
+    assert joined == [strip(a) + strip(b), strip(c)]
+
+
 def test_greedy_free_running_matches_oracle_prefix(tiny_model):
     """Free-running greedy decode: identical ids up to the first step whose oracle margin is within tolerance."""
     m, cfg, ck = tiny_model

@@ -139,6 +139,31 @@ def test_tokenizer_merges_specials_and_utf8(tmp_path):
     assert tok.post_process(tok.decode([4, 20, 6])) == "low"
 
 
+# ---------------------------------------------------------------- long audio
+def test_long_audio_split_points_and_join():
+    from q3asr.segment import frame_rms, join_tokens, segment_batch, split_points
+    sr = 16000
+    rng = np.random.default_rng(7)
+    audio = (rng.standard_normal(sr * 75) * 0.2).astype(np.float32)
+    audio[sr * 27:sr * 27 + 3200] = 0.0                      # a 200 ms pause 3 s before the first limit
+    spans = split_points(audio, sr)
+    assert spans[0][0] == 0 and spans[-1][1] == len(audio)
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))            # exact cover, no overlap
+    assert all(0 < e - s <= 30 * sr for s, e in spans)
+    assert sr * 27 <= spans[0][1] < sr * 27 + 3200                        # the cut lands inside the pause
+    assert frame_rms(audio[spans[0][1]:spans[0][1] + 320], 320)[0] < 0.01
+    fixed = split_points(audio, sr, energy=False)
+    assert [e - s for s, e in fixed] == [30 * sr, 30 * sr, 15 * sr]
+    assert split_points(audio[:sr * 30], sr) == [(0, sr * 30)]            # at the limit: one piece
+    pieces, owner = segment_batch([audio, audio[:sr * 5]], sr, mode="segment_fixed")
+    assert owner == [0, 0, 0, 1] and [len(p) for p in pieces] == [30 * sr, 30 * sr, 15 * sr, 5 * sr]
+    pieces, owner = segment_batch([audio], sr, mode="truncate")
+    assert owner == [0] and len(pieces[0]) == len(audio)                  # the library truncates, as the reference does
+    with pytest.raises(ValueError):
+        segment_batch([audio], sr, mode="overlap")
+    assert join_tokens([[5, 6, 151645], [7, 151643], [9]], [0, 0, 1], 2) == [[5, 6, 7], [9]]
+
+
 # ---------------------------------------------------------------- sharding
 def test_shard_balance_and_cover():
     rng = np.random.default_rng(4321)
