@@ -79,6 +79,21 @@ def pmc_traffic(kernel, args):
     return None, None
 
 
+def measured_copy_ceiling(torch, nbytes=1 << 30, reps=10):
+    """What a plain device-to-device copy reaches on this GPU (read + write bytes per second, GB/s): the practical
+    HBM ceiling beside the vendor peak the roofline fraction is quoted against."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda").random_(0, 255)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,8 +133,15 @@ def main():
     offsets = np.arange(args.batch + 1, dtype=np.int64) * n
 
     def step():
-        return model.transcribe_batch(None, 16000, max_tokens=args.max_tokens, stop_rules=not args.no_stop_rules,
-                                      device_audio=(dev_audio.data_ptr(), offsets))
+        out = model.transcribe_batch(None, 16000, max_tokens=args.max_tokens, stop_rules=not args.no_stop_rules,
+                                     device_audio=(dev_audio.data_ptr(), offsets))
+        if world > 1:
+            # the job's one exchange: every rank ends the batch holding every transcript (token ids)
+            from q3asr.shard import gather_token_lists
+            local = {rank * args.batch + i: t for i, t in enumerate(out.tokens)}
+            everything = gather_token_lists(local, world * args.batch, dist, device="cuda")
+            assert len(everything) == world * args.batch
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -161,6 +183,7 @@ def main():
             ach, peak, unit, bound = per_launch_work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
         ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
         traffic, traffic_src = pmc_traffic(top["name"], args)
+        copy_gbs = measured_copy_ceiling(torch)
         line = {
             "metric": "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips", "value": round(audio_s / dt, 2),
             "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +195,7 @@ def main():
                        "clips_per_gpu": args.batch, "tokens_per_clip": round(tokens / (world * args.batch * args.steps), 1),
                        "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}"},
             "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
+                         "frac": round(ach / peak, 4), "peak_measured_copy": copy_gbs, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
                          "work_per_launch": per_launch_work, "share_of_device_time": round(top["ms_est"] / sum(p["ms_est"] for p in prof), 3)},
             "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
                          "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:8]],

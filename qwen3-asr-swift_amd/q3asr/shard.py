@@ -43,12 +43,12 @@ def gather_token_lists(local, n_total, dist=None, device="cpu"):
     dist.all_gather(metas, meta)
     rows = max(int(m[0]) for m in metas)
     width = max(int(m[1]) for m in metas)
-    buf = torch.full((max(rows, 1), width + 2), -1, dtype=torch.int32, device=device)
+    host = np.full((max(rows, 1), width + 2), -1, dtype=np.int32)     # packed on the host, one upload
     for r, i in enumerate(idx):
-        buf[r, 0] = i
-        buf[r, 1] = len(local[i])
-        if local[i]:
-            buf[r, 2:2 + len(local[i])] = torch.tensor(local[i], dtype=torch.int32)
+        host[r, 0] = i
+        host[r, 1] = len(local[i])
+        host[r, 2:2 + len(local[i])] = local[i]
+    buf = torch.from_numpy(host).to(device)
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf)
     out = [[] for _ in range(n_total)]

@@ -60,6 +60,28 @@ def test_mel_ragged_batch_and_edges(tiny_model):
         assert g.shape[1] == min(len(a) // 160, 3000)
 
 
+def test_mel_full_batch_1024_clips(tiny_model):
+    """The mel-only configuration at its full size, 1024 clips x 30 s in one call (1.97 GB in, 1.57 GB out).  The
+    restatement cannot cover it in seconds, so three clips are checked against it and the rest through properties:
+    a clip's features do not depend on its slot or on its neighbours (64 distinct clips repeated 16 times must give
+    16 bit-identical copies), every clip spans at most 8 decades below its own maximum (range 2.0 after the
+    (x + 4) / 4 scale, AudioPreprocessing.swift:269-288) and nothing is NaN."""
+    m = tiny_model[0]
+    base = [synth.synth_audio(480000, 500 + i, "noise" if i % 8 == 7 else "speechlike") for i in range(64)]
+    clips = [base[i % 64] for i in range(1024)]
+    got = m.feature_extractor.process_batch(clips, 16000)
+    assert len(got) == 1024 and all(g.shape == (128, 3000) for g in got)
+    for i in range(64):
+        for r in range(1, 16):
+            assert np.array_equal(got[i], got[i + 64 * r])
+        assert np.isfinite(got[i]).all()
+        assert got[i].max() - got[i].min() <= 2.0 + 1e-6
+    for i in (0, 7, 63):
+        _check(got[i], base[i], 16000, m)
+    alone = m.feature_extractor.process(base[5], 16000)
+    assert np.array_equal(alone, got[5])
+
+
 def test_mel_test_wav_24k_resample(tiny_model):
     """The reference's own test clip (24 kHz, 20 s) through the linear resampler (AudioPreprocessing.swift:347-365)."""
     audio, rate = read_wav_pcm16(os.path.join(GOLDEN, "test_audio.wav"))
