@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--cpu-decode-steps", type=int, default=128)
     ap.add_argument("--profile-stride", type=int, default=17, help="time every n-th launch with HIP events (odd, so that the "
                     "samples walk through the per-layer launch pattern)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a box with one GPU, together with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -116,13 +119,17 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libq3asr has no CPU path")
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = make_config(args.preset, max_batch=args.batch)
     ck = synth.make_checkpoint(cfg, seed=0)
@@ -139,7 +146,7 @@ def main():
             # the job's one exchange: every rank ends the batch holding every transcript (token ids)
             from q3asr.shard import gather_token_lists
             local = {rank * args.batch + i: t for i, t in enumerate(out.tokens)}
-            everything = gather_token_lists(local, world * args.batch, dist, device="cuda")
+            everything = gather_token_lists(local, world * args.batch, dist, device=coll_dev)
             assert len(everything) == world * args.batch
         return out
 
@@ -161,7 +168,7 @@ def main():
 
     audio_s = sum(o.audio_seconds for o in outs)
     tokens = sum(o.tokens_total for o in outs)
-    stats = torch.tensor([dt, audio_s, float(tokens)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([dt, audio_s, float(tokens)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
