@@ -37,6 +37,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
+// Buffer descriptor over `bytes` bytes at a workgroup-uniform address.  The address goes through
+// readfirstlane so the compiler keeps the descriptor in SGPRs (otherwise every buffer instruction is
+// wrapped in a loop that re-checks its uniformity).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_buffer(const void* base, int bytes) {
+    const uint64_t b = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -63,7 +63,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int kt0 = blockIdx.z * per, kt1 = min(nk_total, kt0 + per);
 
     // ---- per-thread source descriptors ----
-    const bf16_t* a_src[AP];
+    // Plain rows and bf16 weights are read through buffer descriptors based at the tile's first row: a
+    // load then needs a 32-bit per-lane byte offset (fixed) plus a scalar K offset, and no vector ALU work
+    // inside the K loop.  Offsets at or beyond BUF_RANGE read as zero (used for the K tail).
+    constexpr int BUF_RANGE = 0x40000000, BUF_OOB = 0x7f000000;
+    const auto a_rsrc = uniform_buffer(p.A + (AMODE == A_PLAIN ? (int64_t)m0 * p.lda : 0), BUF_RANGE);
+    const auto w_rsrc = uniform_buffer((const bf16_t*)p.W + (WFMT == W_BF16 ? (int64_t)n0 * p.K : 0), BUF_RANGE);
+    int a_voff[AP];
     ConvRow crow[AP];
     int a_koff[AP];
 #pragma unroll
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         a_koff[q] = sc * 8;
         const int m = min(m0 + row, p.M - 1);
         if constexpr (AMODE == A_PLAIN) {
-            a_src[q] = p.A + (int64_t)m * p.lda + sc * 8;
+            a_voff[q] = ((m - m0) * (int)p.lda + sc * 8) * 2;
         } else {
             const int hw = p.Hout * p.Wout;
             const int chunk = m / hw, rem = m - chunk * hw;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             crow[q].wv = min(p.Win, p.win_valid ? p.win_valid[chunk] : p.Win);
         }
     }
-    const bf16_t* w_src[WP];
+    int w_voff[WP];
     int w_koff[WP];
     if constexpr (WFMT == W_BF16) {
 #pragma unroll
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             const int sc = cc ^ f;
             w_koff[q] = sc * 8;
             const int n = min(n0 + row, p.N - 1);
-            w_src[q] = (const bf16_t*)p.W + (int64_t)n * p.K + sc * 8;
+            w_voff[q] = ((n - n0) * p.K + sc * 8) * 2;
         }
     }
 
@@ -102,27 +108,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         char* sa = smem + buf * STAGE;
         char* sw = sa + A_BYTES;
         const int kbase = kt * 64;
+        const bool tail = kbase + 64 > p.K;  // wave-uniform: only the last K tile of a ragged K masks lanes
+        if constexpr (AMODE == A_PLAIN) {
 #pragma unroll
-        for (int q = 0; q < AP; ++q) {
-            const bf16_t* src;
-            const int k0 = kbase + a_koff[q];
-            if constexpr (AMODE == A_PLAIN) {
-                src = (k0 < p.K) ? a_src[q] + kbase : p.zero;
-            } else {
+            for (int q = 0; q < AP; ++q) {
+                const int v = (tail && kbase + a_koff[q] >= p.K) ? BUF_OOB : a_voff[q];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, LDS_PTR(sa + (q * 256 + uwave * 64) * 16), 16, v, kbase * 2, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < AP; ++q) {
+                const int k0 = kbase + a_koff[q];
                 const int khw = k0 / p.Cin, ci = k0 - khw * p.Cin;
                 const int kh = khw / 3, kw = khw - kh * 3;
                 const int iy = crow[q].iy0 + kh, ix = crow[q].ix0 + kw;
                 const bool ok = (k0 < p.K) && iy >= 0 && iy < p.Hin && ix >= 0 && ix < crow[q].wv;
-                src = ok ? p.A + crow[q].base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : p.zero;
+                const bf16_t* src = ok ? p.A + crow[q].base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : p.zero;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sa + (q * 256 + uwave * 64) * 16), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sa + (q * 256 + uwave * 64) * 16), 16, 0, 0);
         }
         if constexpr (WFMT == W_BF16) {
 #pragma unroll
             for (int q = 0; q < WP; ++q) {
-                const int k0 = kbase + w_koff[q];
-                const bf16_t* src = (k0 < p.K) ? w_src[q] + kbase : p.zero;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sw + (q * 256 + uwave * 64) * 16), 16, 0, 0);
+                const int v = (tail && kbase + w_koff[q] >= p.K) ? BUF_OOB : w_voff[q];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(sw + (q * 256 + uwave * 64) * 16), 16, v, kbase * 2, 0, 0);
             }
         } else {
             // MLX affine 4-bit: one u32 = 8 codes = one 16-byte bf16 chunk; dequantised in registers
@@ -372,6 +381,8 @@ void launch_gemm(const GemmParams& p, GemmAMode amode, GemmOut out, GemmWFmt wfm
     Q3_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
     Q3_REQUIRE(p.K % 32 == 0 && p.N % 4 == 0, "gemm: K must be a multiple of 32 and N of 4");
     Q3_REQUIRE(p.zero != nullptr, "gemm: zero page missing");
+    // per-lane byte offsets from a tile's first row must stay inside the buffer descriptors' 1 GB range
+    Q3_REQUIRE((129 * p.lda + p.K) * 2 < (1ll << 30) && 129ll * p.K * 2 < (1ll << 30), "gemm: row stride too large for the buffer range");
     if (amode == A_PLAIN) Q3_REQUIRE(p.lda % 8 == 0 && p.lda >= p.K, "gemm: lda must be >= K and a multiple of 8");
     else Q3_REQUIRE(p.K == 9 * p.Cin && p.Cin % 8 == 0, "gemm: conv K must be 9*Cin, Cin multiple of 8");
     if (wfmt == W_Q4) Q3_REQUIRE(p.qgroup == 64 && p.K % 64 == 0, "gemm: q4 needs group 64 and K multiple of 64");

@@ -73,28 +73,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         for (int u = 0; u < 2; ++u) {
             // A unit u, LDS row q*64 + srow  <-  tile row q*128 + u*64 + srow   (q = reading wave's row half)
             const int m = min(m0 + q * 128 + u * 64 + srow, p.M - 1) - m0;
-            a_off[q][u] = m * (int)p.lda + koff;
+            a_off[q][u] = (m * (int)p.lda + koff) * 2;
             // W unit u, LDS row rho = q*64 + srow = wc*32 + j*16 + i  <-  tile row wc*64 + (i>>2)*16 + u*8 + j*4 + (i&3)
             const int rho = q * 64 + srow, i = rho & 15, j = (rho >> 4) & 1, c = rho >> 5;
             const int n = min(n0 + c * 64 + (i >> 2) * 16 + u * 8 + j * 4 + (i & 3), p.N - 1) - n0;
-            w_off[q][u] = n * p.K + koff;
+            w_off[q][u] = (n * p.K + koff) * 2;
         }
-    // offsets above are relative to the tile's first row, so they fit 32 bits for any operand size
-    const bf16_t* Ap = p.A + (int64_t)m0 * p.lda;
-    const bf16_t* Wp = (const bf16_t*)p.W + (int64_t)n0 * p.K;
+    // Both operands are read through buffer descriptors based at the tile's first row: a load needs the fixed
+    // 32-bit per-lane byte offset above plus a scalar K offset, and no vector ALU work inside the K loop.
+    // Offsets at or beyond BUF_RANGE read as zero (K tail, and the tiles past the end that keep the load counts
+    // uniform).
+    constexpr int BUF_RANGE = 0x40000000, BUF_OOB = 0x7f000000;
+    const auto a_rsrc = uniform_buffer(p.A + (int64_t)m0 * p.lda, BUF_RANGE);
+    const auto w_rsrc = uniform_buffer((const bf16_t*)p.W + (int64_t)n0 * p.K, BUF_RANGE);
     const int lds_lane0 = uwave * 64 * 16;
 
     // unit: 0 = A0, 1 = A1, 2 = W0, 3 = W1
     auto stage = [&](int buf, int unit, int kt) {
         char* dst = smem + buf * BUF + unit * UNIT + lds_lane0;
         const int kbase = kt * 64;
-        const bool ok = kt < kt1 && kbase + koff < p.K;
+        const bool past = kt >= kt1, tail = kbase + 64 > p.K;  // wave-uniform
+        const bool masked = past || (tail && kbase + koff >= p.K);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const bf16_t* src;
-            if (unit < 2) src = ok ? Ap + (a_off[q][unit] + kbase) : p.zero;
-            else src = ok ? Wp + (w_off[q][unit - 2] + kbase) : p.zero;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + q * 512 * 16), 16, 0, 0);
+            const int v = masked ? BUF_OOB : (unit < 2 ? a_off[q][unit] : w_off[q][unit - 2]);
+            if (unit < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, LDS_PTR(dst + q * 512 * 16), 16, v, past ? 0 : kbase * 2, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(dst + q * 512 * 16), 16, v, past ? 0 : kbase * 2, 0, 0);
         }
     };
 
@@ -298,8 +302,8 @@ void launch_o(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 void launch_gemm256(const GemmParams& p, GemmOut out, hipStream_t s) {
-    // staging offsets are 32-bit element indices relative to a tile's first row
-    Q3_REQUIRE(256 * p.lda + p.K < (1ll << 31) && 257ll * p.K < (1ll << 31), "gemm256: row stride too large for 32-bit offsets");
+    // staging offsets are byte offsets from a tile's first row and must stay inside the descriptors' 1 GB range
+    Q3_REQUIRE((256 * p.lda + p.K) * 2 < (1ll << 30) && 257ll * p.K * 2 < (1ll << 30), "gemm256: row stride too large for the buffer range");
     switch (out) {
         case OUT_BF16: launch_o<OUT_BF16>(p, s); break;
         case OUT_F32: launch_o<OUT_F32>(p, s); break;
