@@ -115,6 +115,11 @@ int q3asr_profile_stop(q3asr_model* m, char* json_out, int capacity);
  * q3asr_op_gemm: out[M][N] fp32 = act(A[M][K] * W[N][K]^T + bias), bf16 operands; tile / ksplit select the kernel variant. */
 int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const float* bias, int M, int N, int K, int gelu,
                   int tile, int ksplit, float* out);
+/* q3asr_op_greedy_rules: the greedy loop's bookkeeping and stop rules alone (Qwen3ASR.swift:388-389, 567-627) on given
+ * per-step argmax results: picks[step][utt] (step 0 = the prefill's token), seen0[utt] = 1 for a forced-language prompt (:565-566).
+ * Writes each utterance's kept tokens [utt][max_tokens] and their count. */
+int q3asr_op_greedy_rules(q3asr_model* m, const int32_t* picks, const int32_t* seen0, int n_utt, int steps, int max_tokens,
+                          int stop_rules, int32_t* tokens_out, int32_t* n_tokens_out);
 /* q3asr_op_gemm_time: average milliseconds per launch of the GEMM kernel variant (tile: 0 128x128, 1 64x64, 2 128x64,
  * 3 256x256, -1 automatic; out_kind: 0 bf16, 1 f32, 2 f32 accumulate, 3 SwiGLU, 4 argmax partials, 5 split-K slabs) on
  * device-resident pseudo-random bf16 operands, HIP events on the model's stream.  A measurement hook with no

@@ -186,6 +186,32 @@ int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const fl
     Q3_API_END
 }
 
+int q3asr_op_greedy_rules(q3asr_model* m, const int32_t* picks, const int32_t* seen0, int n_utt, int steps, int max_tokens,
+                          int stop_rules, int32_t* tokens_out, int32_t* n_tokens_out) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && picks && tokens_out && n_tokens_out && n_utt > 0 && steps > 0 && max_tokens > 0, "op_greedy_rules: bad argument");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    const size_t B = (size_t)n_utt;
+    int* d_picks = m->arena.get<int>(B * steps);
+    int* d_tokens = m->arena.get<int>(B * max_tokens);
+    int* d_state = m->arena.get<int>(B * 5 + 64);  // ntok, done, seen, next, len, n_active
+    HIP_CHECK(hipMemcpyAsync(d_picks, picks, B * steps * 4, hipMemcpyHostToDevice, m->stream));
+    HIP_CHECK(hipMemsetAsync(d_tokens, 0, B * max_tokens * 4, m->stream));
+    HIP_CHECK(hipMemsetAsync(d_state, 0, (B * 5 + 64) * 4, m->stream));
+    if (seen0) HIP_CHECK(hipMemcpyAsync(d_state + 2 * B, seen0, B * 4, hipMemcpyHostToDevice, m->stream));
+    // picks are stored step-major so that each step's argmax row is contiguous
+    for (int t = 0; t < steps; ++t) {
+        StepParams sp{d_picks + (size_t)t * B, d_tokens, d_state, d_state + B, d_state + 2 * B, d_state + 3 * B, d_state + 4 * B,
+                      d_state + 5 * B, nullptr, n_utt, max_tokens, t ? 1 : 0, stop_rules};
+        launch_step(sp, m->stream);
+    }
+    HIP_CHECK(hipMemcpyAsync(tokens_out, d_tokens, B * max_tokens * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipMemcpyAsync(n_tokens_out, d_state, B * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    Q3_API_END
+}
+
 int q3asr_op_gemm_time(q3asr_model* m, int M, int N, int K, int tile, int ksplit, int out_kind, int iters, float* ms_per_call) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && ms_per_call && iters > 0 && out_kind >= 0 && out_kind <= 5, "op_gemm_time: bad argument");

@@ -328,14 +328,16 @@ __global__ __launch_bounds__(256) void step_kernel(StepParams p) {
             bool stop = false;
             if (p.stop_rules) {
                 const int seen = p.seen_asr[u];
-                // breaks evaluated right after the append: Qwen3ASR.swift:597-627
-                if (tok == TOK_IM_START || tok == TOK_AUDIO_START || tok == TOK_AUDIO_END || tok == TOK_AUDIO_PAD) stop = true;
-                if (!stop && seen && n >= 32) {
+                // breaks evaluated right after the append: Qwen3ASR.swift:597-627.  They sit inside the decode loop,
+                // so the prefill's token (:388-389, advance == 0 here) is appended without them.
+                const bool in_loop = p.advance != 0;
+                if (in_loop && (tok == TOK_IM_START || tok == TOK_AUDIO_START || tok == TOK_AUDIO_END || tok == TOK_AUDIO_PAD)) stop = true;
+                if (!stop && in_loop && seen && n >= 32) {
                     int run = 0;
                     for (int i = n - 1; i >= 0 && toks[i] == tok; --i) ++run;
                     if (run >= 16) stop = true;
                 }
-                if (!stop && seen && n >= 64) {
+                if (!stop && in_loop && seen && n >= 64) {
                     int uniq[5], nu = 0;
                     for (int i = n - 64; i < n && nu <= 4; ++i) {
                         bool found = false;

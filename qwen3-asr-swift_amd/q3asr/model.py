@@ -270,6 +270,19 @@ class Qwen3ASRModel:
                                                       M, N, K, int(gelu), tile, ksplit, out.ctypes.data))
         return out
 
+    def op_greedy_rules(self, picks, seen0=None, max_tokens=448, stop_rules=True):
+        """picks: int32 [n_utt, steps] argmax results per step (column 0 = the prefill's token).  Returns the token lists
+        the device-side greedy bookkeeping keeps."""
+        picks = np.ascontiguousarray(np.asarray(picks, dtype=np.int32))
+        n, steps = picks.shape
+        by_step = np.ascontiguousarray(picks.T)
+        seen = None if seen0 is None else np.ascontiguousarray(seen0, dtype=np.int32)
+        toks = np.zeros((n, max_tokens), dtype=np.int32)
+        cnt = np.zeros(n, dtype=np.int32)
+        _lib.check(self._lib, self._lib.q3asr_op_greedy_rules(self._h, by_step.ctypes.data, None if seen is None else seen.ctypes.data,
+                                                              n, steps, int(max_tokens), int(stop_rules), toks.ctypes.data, cnt.ctypes.data))
+        return [toks[i, :cnt[i]].tolist() for i in range(n)]
+
     def op_gemm_time(self, M, N, K, tile=-1, ksplit=1, out_kind=0, iters=20):
         """Average ms per launch of one GEMM kernel variant on device-resident random operands."""
         ms = ctypes.c_float()

@@ -95,3 +95,68 @@ def test_attention_matches_fp64(tiny_model, lens, heads, group, hd, causal):
     out = bf16_vals(m.op_attention(q, k, v, cu, heads, group, hd, causal))
     ref = _ref_attention(bf16_vals(q), bf16_vals(k), bf16_vals(v), cu, heads, group, hd, causal)
     assert np.abs(out - ref).max() <= 2e-2     # P and O are rounded to bf16
+
+
+def _rules_reference(picks, seen, max_tokens):
+    """The reference's loop (Qwen3ASR.swift:388-389, 567-627) driven by given argmax results, via the restatement's rules."""
+    import oracle
+    g = oracle.generate
+    tokens = [int(picks[0])]
+    nxt = tokens[0]
+    for it in range(1, max_tokens):
+        if nxt in (g.IM_END, g.ENDOFTEXT):
+            break
+        if nxt == g.ASR_TEXT:
+            seen = True
+        if it >= len(picks):
+            break
+        nxt = int(picks[it])
+        tokens.append(nxt)
+        if g.stop_after_append(tokens, seen):
+            break
+    return tokens
+
+
+def test_greedy_stop_rules_on_device(tiny_model):
+    """Device-side bookkeeping of the greedy loop against the restatement on crafted and random argmax sequences:
+    EOS kept then stop, control tokens (not applied to the prefill's token), 16-run after 32 tokens, <= 4 unique in
+    the last 64, both only once <asr_text> was seen or the language was forced, and the max_tokens cap."""
+    import oracle
+    g = oracle.generate
+    m = tiny_model[0]
+    rng = np.random.default_rng(2024)
+    T = 100
+    rows, seen0 = [], []
+
+    def add(seq, seen=0):
+        seq = list(seq) + [7] * T
+        rows.append(seq[:T])
+        seen0.append(seen)
+
+    add([5, 6, g.IM_END, 9, 9])                                   # EOS appended, then stop
+    add([g.ENDOFTEXT, 3, 3])                                      # EOS as the prefill's token
+    add([g.AUDIO_PAD, 3, g.AUDIO_PAD, 4])                         # control token: ignored at step 0, stops at step 2
+    add([1, 2, g.IM_START, 4])
+    add([1, g.AUDIO_START, 4])
+    add([1, 2, 3, g.AUDIO_END])
+    add([g.ASR_TEXT] + list(range(100, 120)) + [55] * 40)         # run of 16 reached at n = 37 >= 32
+    add(list(range(100, 121)) + [55] * 40)                        # same without <asr_text>: no stop
+    add(list(range(100, 121)) + [55] * 40, seen=1)                # forced language arms the rules from the start
+    add([g.ASR_TEXT] + [55] * 40)                                 # run long before n = 32: stops exactly at n = 32
+    add([g.ASR_TEXT] + [t for _ in range(40) for t in (11, 12, 13)])        # <= 4 unique in the last 64
+    add([g.ASR_TEXT] + [t for _ in range(40) for t in (11, 12, 13, 14, 15)])  # 5 unique: no stop
+    add([t for _ in range(40) for t in (11, 12, 13)], seen=0)     # rule not armed
+    add(list(rng.integers(0, 6, size=T)), seen=1)                 # random low-diversity streams
+    add(list(rng.integers(0, 3, size=T)), seen=1)
+    add([g.ASR_TEXT] + list(rng.integers(0, 4, size=T)))
+    for _ in range(40):
+        seq = rng.integers(0, 30, size=T)
+        seq[rng.integers(0, T, size=3)] = rng.choice([g.IM_END, g.ENDOFTEXT, g.ASR_TEXT, g.AUDIO_PAD, g.IM_START], size=3)
+        add(list(seq), seen=int(rng.integers(0, 2)))
+    picks = np.array(rows, dtype=np.int32)
+    for max_tokens in (100, 40, 1):
+        got = m.op_greedy_rules(picks, seen0, max_tokens=max_tokens)
+        for i in range(len(rows)):
+            assert got[i] == _rules_reference(picks[i], bool(seen0[i]), max_tokens), (i, max_tokens)
+    free = m.op_greedy_rules(picks, seen0, max_tokens=100, stop_rules=False)
+    assert all(len(t) == 100 for t in free)
