@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--cpu-decode-steps", type=int, default=128)
     ap.add_argument("--profile-stride", type=int, default=17, help="time every n-th launch with HIP events (odd, so that the "
                     "samples walk through the per-layer launch pattern)")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP-event timing (and no roofline object): what a "
+                    "latency measurement of small groups needs, since timed launches are not replayed as a graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with one GPU, together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -158,13 +160,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    model.profile_start(args.profile_stride)
+    if not args.no_profile:
+        model.profile_start(args.profile_stride)
     fence()
     t0 = time.perf_counter()
     outs = [step() for _ in range(args.steps)]
     fence()
     dt = time.perf_counter() - t0
-    prof = model.profile_stop()
+    prof = [] if args.no_profile else model.profile_stop()
 
     audio_s = sum(o.audio_seconds for o in outs)
     tokens = sum(o.tokens_total for o in outs)
@@ -176,7 +179,17 @@ def main():
         dt = float(tmax[0])
     audio_s, tokens = float(stats[1]), float(stats[2])
 
-    if rank == 0:
+    if rank == 0 and not prof:
+        ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
+        print(json.dumps({"metric": "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips", "value": round(audio_s / dt, 2),
+                          "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"latency run without kernel timing, {args.batch} x {args.clip_seconds:g} s clips, "
+                                                 f"max_tokens {args.max_tokens}", "clips_per_gpu": args.batch,
+                                     "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    elif rank == 0:
         # dominant kernel by device time (sampled HIP-event timings scaled to all launches)
         for p in prof:
             p["ms_est"] = p["ms_timed"] * p["launches"] / max(p["timed"], 1)
