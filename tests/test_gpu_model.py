@@ -123,6 +123,32 @@ def test_batch_equals_single_and_order(pinned_model):
     assert abs(batch.audio_seconds - sum(len(a) for a in audios) / 16000.0) < 1e-6
 
 
+def test_ragged_corpus_in_groups(monkeypatch):
+    """40 utterances of 0.2-33 s through a model that decodes at most 12 at a time: several length-sorted groups,
+    results back in request order, audio-token counts by the reference's length algebra (AudioEncoder.swift:254-270),
+    and every fifth utterance identical to its own single-utterance run."""
+    for k, v in (("Q3ASR_DECODE_TILE", "1"), ("Q3ASR_DECODE_SPLIT", "1"), ("Q3ASR_DECODE_NO_FUSE", "1")):
+        monkeypatch.setenv(k, v)        # one kernel variant for every group size (see conftest.pinned_model)
+    cfg = make_config("tiny", max_batch=12)
+    ck = synth.make_checkpoint(cfg, seed=1)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        rng = np.random.default_rng(77)
+        lens = [int(x) for x in rng.uniform(0.2, 33.0, size=40) * 16000]
+        lens[3], lens[17] = 160 * 100, 160 * 3000 + 159            # exactly one chunk; exactly 3000 frames
+        audios = [synth.synth_audio(n, 400 + i) for i, n in enumerate(lens)]
+        out = m.transcribe_batch(audios, 16000, max_tokens=6, stop_rules=False)
+        assert len(out.tokens) == 40 and all(len(t) == 6 for t in out.tokens)
+        for i, n in enumerate(lens):
+            assert int(out.n_audio_tokens[i]) == oracle.encoder.output_length(min(n // 160, 3000))
+        assert abs(out.audio_seconds - sum(min(n, 480000) for n in lens) / 16000.0) < 1e-6
+        for i in range(0, 40, 5):
+            single = m.transcribe_batch([audios[i]], 16000, max_tokens=6, stop_rules=False)
+            assert single.tokens[0] == out.tokens[i], i
+    finally:
+        m.close()
+
+
 def test_two_stream_decode_equals_one_stream(pinned_model, monkeypatch):
     """Large groups are decoded as two halves on two event-chained streams; a small group is forced through that
     path here and must give the tokens (and stop points) of the single-stream loop."""
