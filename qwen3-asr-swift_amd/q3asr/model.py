@@ -154,6 +154,14 @@ class Qwen3ASRModel:
                          ("vocab_size", "vocab"), ("rms_norm_eps", "rms_eps"), ("rope_theta", "rope_theta")):
             if src in tc:
                 kw[dst] = tc[src]
+        # The reference keeps its built-in encoder shape (AudioEncoder.swift:26-43); a checkpoint's own audio_config,
+        # when present (HF layout: thinker_config.audio_config), is what the 1.7B model needs.
+        ac = cj.get("thinker_config", cj).get("audio_config", {})
+        for src, dst in (("d_model", "enc_d_model"), ("encoder_layers", "enc_layers"), ("encoder_attention_heads", "enc_heads"),
+                         ("encoder_ffn_dim", "enc_ffn"), ("output_dim", "enc_out_dim"), ("downsample_hidden_size", "conv_channels"),
+                         ("num_mel_bins", "n_mels"), ("n_window", "n_window"), ("n_window_infer", "n_window_infer")):
+            if src in ac:
+                kw[dst] = ac[src]
         kw.update(overrides)
         m = cls(make_config(preset, **kw), device)
         m.load_checkpoint(load_dir(model_dir))
