@@ -204,6 +204,7 @@ def main():
         ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
         traffic, traffic_src = pmc_traffic(top["name"], args)
         copy_gbs = measured_copy_ceiling(torch)
+        read_gbs = round(model.op_read_bandwidth(1 << 32), 1)   # streaming read of 4 GiB: what an HBM-read-bound kernel can reach
         line = {
             "metric": "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips", "value": round(audio_s / dt, 2),
             "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -215,7 +216,7 @@ def main():
                        "clips_per_gpu": args.batch, "tokens_per_clip": round(tokens / (world * args.batch * args.steps), 1),
                        "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}"},
             "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                         "frac": round(ach / peak, 4), "peak_measured_copy": copy_gbs, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
+                         "frac": round(ach / peak, 4), "peak_measured_copy": copy_gbs, "peak_measured_read": read_gbs, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
                          "work_per_launch": per_launch_work, "share_of_device_time": round(top["ms_est"] / sum(p["ms_est"] for p in prof), 3)},
             "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
                          "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:8]],

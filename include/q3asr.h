@@ -120,6 +120,9 @@ int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const fl
  * Writes each utterance's kept tokens [utt][max_tokens] and their count. */
 int q3asr_op_greedy_rules(q3asr_model* m, const int32_t* picks, const int32_t* seen0, int n_utt, int steps, int max_tokens,
                           int stop_rules, int32_t* tokens_out, int32_t* n_tokens_out);
+/* q3asr_op_read_bandwidth: GB/s of a plain streaming read of `bytes` bytes of device memory (the practical HBM read
+ * ceiling reported beside the vendor peak in the benchmark's roofline; a measurement hook, no counterpart in the reference). */
+int q3asr_op_read_bandwidth(q3asr_model* m, int64_t bytes, float* gb_per_s);
 /* q3asr_op_gemm_time: average milliseconds per launch of the GEMM kernel variant (tile: 0 128x128, 1 64x64, 2 128x64,
  * 3 256x256, -1 automatic; out_kind: 0 bf16, 1 f32, 2 f32 accumulate, 3 SwiGLU, 4 argmax partials, 5 split-K slabs) on
  * device-resident pseudo-random bf16 operands, HIP events on the model's stream.  A measurement hook with no

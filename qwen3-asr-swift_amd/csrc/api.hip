@@ -212,6 +212,22 @@ int q3asr_op_greedy_rules(q3asr_model* m, const int32_t* picks, const int32_t* s
     Q3_API_END
 }
 
+int q3asr_op_read_bandwidth(q3asr_model* m, int64_t bytes, float* gb_per_s) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && gb_per_s && bytes >= (1 << 20) && bytes % 16 == 0, "op_read_bandwidth: bad argument");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    char* buf = m->arena.get<char>((size_t)bytes);
+    launch_fill_bf16((bf16_t*)buf, (size_t)bytes / 2, 0x77u, m->stream);
+    float best = 0.f;
+    for (int blocks : {2048, 4096, 8192}) {
+        const float ms = read_probe_ms(buf, (size_t)bytes, blocks, 5, m->stream);
+        best = std::max(best, (float)((double)bytes / (ms * 1e-3) / 1e9));
+    }
+    *gb_per_s = best;
+    Q3_API_END
+}
+
 int q3asr_op_gemm_time(q3asr_model* m, int M, int N, int K, int tile, int ksplit, int out_kind, int iters, float* ms_per_call) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && ms_per_call && iters > 0 && out_kind >= 0 && out_kind <= 5, "op_gemm_time: bad argument");

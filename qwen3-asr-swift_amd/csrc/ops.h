@@ -100,5 +100,9 @@ void launch_step(const StepParams& p, hipStream_t s);
 // columns): out[row][j] = silu(sum_s gate) * (sum_s up), bf16 [rows][n2 / 2].
 void launch_swiglu_reduce(const float* slab, int nslab, int64_t slab_stride, int rows, int n2, bf16_t* out, hipStream_t s);
 
+// Average milliseconds of one streaming read of `bytes` bytes (16-byte loads, `blocks` workgroups): the HBM read
+// rate this GPU reaches, measured beside the kernels that are bound by it.
+float read_probe_ms(const void* p, size_t bytes, int blocks, int reps, hipStream_t s);
+
 // Pseudo-random bf16 values in (-1, 1) for the kernel timing entry points.
 void launch_fill_bf16(bf16_t* p, size_t n, uint32_t seed, hipStream_t s);

@@ -291,6 +291,12 @@ class Qwen3ASRModel:
                                                               n, steps, int(max_tokens), int(stop_rules), toks.ctypes.data, cnt.ctypes.data))
         return [toks[i, :cnt[i]].tolist() for i in range(n)]
 
+    def op_read_bandwidth(self, nbytes=1 << 32):
+        """GB/s of a plain streaming read of device memory (practical HBM read ceiling)."""
+        v = ctypes.c_float()
+        _lib.check(self._lib, self._lib.q3asr_op_read_bandwidth(self._h, int(nbytes), ctypes.byref(v)))
+        return v.value
+
     def op_gemm_time(self, M, N, K, tile=-1, ksplit=1, out_kind=0, iters=20):
         """Average ms per launch of one GEMM kernel variant on device-resident random operands."""
         ms = ctypes.c_float()
