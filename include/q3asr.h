@@ -1,7 +1,7 @@
 /* libq3asr -- C ABI of the MI355X (gfx950) Qwen3-ASR offline-transcription hot path.
  *
  * The reference (seichris/qwen3-asr-swift) has no FFI seam for this path: its Swift modules call
- * MLX directly.  This header is the seam a Swift host would bind: the host
+ * MLX directly.  This header is the seam a Swift host would bind through a system-library module map: the host
  * keeps Qwen3ASRModel.fromPretrained / transcribe(audio:sampleRate:) and its safetensors loader and
  * calls these entry points.  Every declaration cites the reference code it replaces, as
  * Sources/Qwen3ASR/<file>:<lines>.

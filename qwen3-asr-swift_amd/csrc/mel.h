@@ -8,7 +8,7 @@ constexpr int MEL_TILE_FRAMES = 64;
 
 struct MelTables {           // device-resident constants, built once per model
     float* hann = nullptr;   // [208]  periodic Hann, zero beyond n = 200
-    float* twid = nullptr;   // [51][2][13][64] MFMA B-fragments of the folded DFT
+    float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT
     int* fb_lo = nullptr;    // [128] first FFT bin of each mel filter
     int* fb_cnt = nullptr;   // [128] number of bins
     int* fb_off = nullptr;   // [128] offset into fb_w

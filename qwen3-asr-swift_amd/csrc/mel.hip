@@ -4,11 +4,12 @@
 // One workgroup = 64 frames of one utterance.  The 10 480 samples those frames cover are staged
 // once in LDS (coalesced, reflect padding resolved on load).  Because the frame is real, the
 // 400-point DFT folds to Re X[k] = sum_{n<=200} h[n](x[n] + x[400-n]) cos(2 pi k n / 400) and
-// Im X[k] = -sum h[n](x[n] - x[400-n]) sin(...): two [frames x 201] x [201 x 201] real products,
-// half the direct DFT's multiplies, evaluated on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32,
-// an fp32 fma chain).  A further even/odd-sample split would halve the work again but aliases
-// bin k onto 200-k inside the partial sums and costs ~1e-4 of accuracy near the max-8 floor, so it
-// is not used.  Power, the sparse
+// Im X[k] = -sum h[n](x[n] - x[400-n]) sin(...); splitting those sums into even and odd n gives four
+// [frames x 101] x [101 x 101] real products (Ce, Co, Se, So over bins 0..100) from which bin k is
+// (Ce + Co, Se + So) and bin 200 - k is (Ce - Co, Se - So): a quarter of the direct DFT's multiplies,
+// evaluated on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, an fp32 fma chain).  The difference form
+// loses accuracy only where bin 200 - k is far weaker than bin k: relative error ~6e-8 * |X[k]| / |X[200-k]|,
+// i.e. < 1e-5 of log-mel for a 60 dB spread between the halves of the spectrum.  Power, the sparse
 // slaney filterbank, log10 and a per-utterance running maximum (wave reduction + one atomic per
 // workgroup) follow without leaving the CU.  Output is the raw log10 mel; the max-8 clamp and
 // (x+4)/4 scale need the utterance-wide maximum and are applied by the consumer (conv1) or by
@@ -22,16 +23,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-constexpr int KSTEPS = 51;     // 204 >= 201 folded taps, 4 per MFMA
-constexpr int NTILES = 13;     // 208 >= 201 bins
+constexpr int KSTEPS = 26;     // 104 >= 101 folded taps of each parity, 4 per MFMA
+constexpr int NTILES = 7;      // 112 >= 101 bins
 constexpr int SAMPLES = MEL_TILE_FRAMES * MEL_HOP + (MEL_NFFT - MEL_HOP) + 1;  // 10481
 constexpr int POW_STRIDE = MEL_NBINS;
-constexpr int REGION = MEL_TILE_FRAMES * POW_STRIDE;  // 12864 floats >= skewed sample image (10481 + 132)
+constexpr int REGION = MEL_TILE_FRAMES * POW_STRIDE;  // 12864 floats >= skewed sample image (10481 + 133)
 constexpr int HANN_N = 208;
 
 __device__ __forceinline__ int skew(int p) {
     const int q = p / MEL_HOP;
-    return p + 2 * q;  // frame starts land on banks 2*frame: conflict-free fragment reads
+    return p + 4 * (q >> 1) + (q & 1);  // frame starts land on distinct banks for the stride-2 fragment reads
 }
 
 __device__ __forceinline__ unsigned enc_max(float f) {
@@ -76,41 +77,49 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     __syncthreads();
 
     // ---- folded DFT on the fp32 MFMA: wave w owns frames 16w .. 16w+15 ----
-    f32x4 acc[2][NTILES];
+    f32x4 acc[4][NTILES];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < NTILES; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, lg = lane >> 4;
     const int s0 = (16 * wave + li) * MEL_HOP;
     const float* tw = twid + lane;
     for (int s = 0; s < KSTEPS; ++s) {
-        const int n = 4 * s + lg;
-        const float xa = sm[skew(s0 + n)], xb = sm[skew(s0 + MEL_NFFT - n)];
-        const float h = hann[n];
-        float av[2];
-        av[0] = h * (xa + xb);  // cosine (real) part
-        av[1] = h * (xa - xb);  // sine (imaginary) part
+        const int e = 2 * (4 * s + lg);
+        const float xa = sm[skew(s0 + e)], xb = sm[skew(s0 + MEL_NFFT - e)];
+        const float xc = sm[skew(s0 + e + 1)], xd = sm[skew(s0 + MEL_NFFT - 1 - e)];
+        const float he = hann[e], ho = hann[e + 1];
+        float av[4];
+        av[0] = he * (xa + xb);  // even samples, cosine part
+        av[1] = ho * (xc + xd);  // odd samples, cosine part
+        av[2] = he * (xa - xb);  // even samples, sine part
+        av[3] = ho * (xc - xd);  // odd samples, sine part
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
+        for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
             for (int nt = 0; nt < NTILES; ++nt) {
-                const float b = tw[((s * 2 + pr) * NTILES + nt) * 64];
+                const float b = tw[((s * 4 + pr) * NTILES + nt) * 64];
                 acc[pr][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr], b, acc[pr][nt], 0, 0, 0);
             }
     }
     __syncthreads();  // every wave is done with the sample image; reuse it for the power spectrum
 
-    // ---- power spectrum |X[k]|^2 (AudioPreprocessing.swift:207) ----
+    // ---- power spectrum |X[k]|^2 (AudioPreprocessing.swift:207): bins k and 200-k from the same four sums ----
 #pragma unroll
     for (int nt = 0; nt < NTILES; ++nt) {
         const int k = 16 * nt + li;
-        if (k <= 200) {
+        if (k <= 100) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int fr = 16 * wave + 4 * lg + r;
-                const float re = acc[0][nt][r], im = acc[1][nt][r];
+                const float ce = acc[0][nt][r], co = acc[1][nt][r], se = acc[2][nt][r], so = acc[3][nt][r];
+                const float re = ce + co, im = se + so;
                 sm[fr * POW_STRIDE + k] = re * re + im * im;
+                if (k < 100) {
+                    const float re2 = ce - co, im2 = se - so;
+                    sm[fr * POW_STRIDE + 200 - k] = re2 * re2 + im2 * im2;
+                }
             }
         }
     }
@@ -202,24 +211,25 @@ void mel_tables_create(MelTables& t) {
     t.hann = upload(hann);
 
     // Folded DFT tables as MFMA B-fragments: lane (g = lane>>4, j = lane&15) of step s, product pr,
-    // bin tile nt holds T_pr[n][k] with n = 4 s + g, k = 16 nt + j.  Angles are reduced (k n mod 400)
-    // and evaluated in double: the mathematically exact twiddles.
-    std::vector<float> tw((size_t)KSTEPS * 2 * NTILES * 64, 0.f);
+    // bin tile nt holds T_pr[n][k] with k = 16 nt + j and n = 2 (4 s + g) (+1 for the odd products).
+    // Angles are reduced (k n mod 400) and evaluated in double: the mathematically exact twiddles.
+    std::vector<float> tw((size_t)KSTEPS * 4 * NTILES * 64, 0.f);
     for (int s = 0; s < KSTEPS; ++s)
-        for (int pr = 0; pr < 2; ++pr)
+        for (int pr = 0; pr < 4; ++pr)
             for (int nt = 0; nt < NTILES; ++nt)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int g = lane >> 4, j = lane & 15, k = 16 * nt + j, n = 4 * s + g;
+                    const int g = lane >> 4, j = lane & 15, k = 16 * nt + j;
+                    const int n = 2 * (4 * s + g) + (pr & 1);
                     float v = 0.f;
-                    const bool cosine = pr == 0;
+                    const bool cosine = pr < 2;
                     const bool n_ok = cosine ? n <= 200 : (n >= 1 && n <= 199);
-                    if (k <= 200 && n_ok) {
+                    if (k <= 100 && n_ok) {
                         const double ang = 2.0 * PI * (double)((k * n) % MEL_NFFT) / (double)MEL_NFFT;
                         double val = cosine ? cos(ang) : sin(ang);
                         if (cosine && n == 200) val *= 0.5;  // the fold counts the centre tap twice
                         v = (float)val;
                     }
-                    tw[(((size_t)s * 2 + pr) * NTILES + nt) * 64 + lane] = v;
+                    tw[(((size_t)s * 4 + pr) * NTILES + nt) * 64 + lane] = v;
                 }
     t.twid = upload(tw);
 
