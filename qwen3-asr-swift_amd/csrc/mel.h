@@ -4,15 +4,14 @@
 #include <vector>
 
 constexpr int MEL_NFFT = 400, MEL_HOP = 160, MEL_NMELS = 128, MEL_NBINS = 201, MEL_MAX_FRAMES = 3000;
+constexpr int MEL_FB_WIDTH = 12;  // widest slaney filter at 16 kHz / 400-point FFT spans 9 bins
 constexpr int MEL_TILE_FRAMES = 64;
 
 struct MelTables {           // device-resident constants, built once per model
     float* hann = nullptr;   // [208]  periodic Hann, zero beyond n = 200
     float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT
     int* fb_lo = nullptr;    // [128] first FFT bin of each mel filter
-    int* fb_cnt = nullptr;   // [128] number of bins
-    int* fb_off = nullptr;   // [128] offset into fb_w
-    float* fb_w = nullptr;   // packed non-zero filter weights
+    float* fb_dense = nullptr;  // [128][MEL_FB_WIDTH] filter weights from fb_lo on, zero after the filter's last bin
     std::vector<float> host_fb;  // dense [128][201] filterbank (host copy, for inspection / tests)
 };
 

@@ -47,8 +47,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
                                                   const int64_t* __restrict__ d_len, const int* __restrict__ tile_utt,
                                                   const int* __restrict__ tile_f0, const float* __restrict__ hann_g,
                                                   const float* __restrict__ twid, const int* __restrict__ fb_lo,
-                                                  const int* __restrict__ fb_cnt, const int* __restrict__ fb_off,
-                                                  const float* __restrict__ fb_w, float* __restrict__ out, int t_stride,
+                                                  const float* __restrict__ fb_dense, float* __restrict__ out, int t_stride,
                                                   unsigned* __restrict__ d_max) {
     __shared__ __attribute__((aligned(16))) float sm[REGION + HANN_N + 4];
     float* hann = sm + REGION;
@@ -130,11 +129,16 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     const int frame = f0 + f;
     const float* pw = sm + f * POW_STRIDE;
     float vmax = -INFINITY;
-    for (int m = mg; m < MEL_NMELS; m += 4) {
-        const int lo = fb_lo[m], cnt = fb_cnt[m];
-        const float* w = fb_w + fb_off[m];
+    // Every filter is stored MEL_FB_WIDTH wide (zero weights after its last bin), so the table reads are
+    // wave-uniform loads of fixed size that do not depend on one another; the zero terms leave the sum unchanged.
+#pragma unroll 4
+    for (int i = 0; i < MEL_NMELS / 4; ++i) {
+        const int m = mg * (MEL_NMELS / 4) + i;
+        const int lo = fb_lo[m];
+        const float* w = fb_dense + m * MEL_FB_WIDTH;
         float sum = 0.f;
-        for (int c = 0; c < cnt; ++c) sum = fmaf(pw[lo + c], w[c], sum);
+#pragma unroll
+        for (int c = 0; c < MEL_FB_WIDTH; ++c) sum = fmaf(pw[lo + c], w[c], sum);
         const float v = log10f(fmaxf(sum, 1e-10f));
         if (frame < frames_total) vmax = fmaxf(vmax, v);
         if (frame < frames_out) out[((int64_t)u * MEL_NMELS + m) * t_stride + frame] = v;
@@ -234,8 +238,8 @@ void mel_tables_create(MelTables& t) {
     t.twid = upload(tw);
 
     t.host_fb = build_filterbank();
-    std::vector<int> lo(MEL_NMELS), cnt(MEL_NMELS), off(MEL_NMELS);
-    std::vector<float> w;
+    std::vector<int> lo(MEL_NMELS);
+    std::vector<float> dense((size_t)MEL_NMELS * MEL_FB_WIDTH, 0.f);
     for (int m = 0; m < MEL_NMELS; ++m) {
         int first = -1, last = -1;
         for (int b = 0; b < MEL_NBINS; ++b)
@@ -244,21 +248,16 @@ void mel_tables_create(MelTables& t) {
                 last = b;
             }
         if (first < 0) first = 0, last = -1;
+        Q3_REQUIRE(last - first + 1 <= MEL_FB_WIDTH, "mel: a filter spans more FFT bins than the kernel's table width");
         lo[m] = first;
-        cnt[m] = last - first + 1;
-        off[m] = (int)w.size();
-        for (int b = first; b <= last; ++b) w.push_back(t.host_fb[(size_t)m * MEL_NBINS + b]);
+        for (int b = first; b <= last; ++b) dense[(size_t)m * MEL_FB_WIDTH + (b - first)] = t.host_fb[(size_t)m * MEL_NBINS + b];
     }
-    if (w.empty()) w.push_back(0.f);
     t.fb_lo = upload(lo);
-    t.fb_cnt = upload(cnt);
-    t.fb_off = upload(off);
-    t.fb_w = upload(w);
+    t.fb_dense = upload(dense);
 }
 
 void mel_tables_destroy(MelTables& t) {
-    (void)hipFree(t.hann); (void)hipFree(t.twid); (void)hipFree(t.fb_lo);
-    (void)hipFree(t.fb_cnt); (void)hipFree(t.fb_off); (void)hipFree(t.fb_w);
+    (void)hipFree(t.hann); (void)hipFree(t.twid); (void)hipFree(t.fb_lo); (void)hipFree(t.fb_dense);
     t = MelTables();
 }
 
@@ -273,7 +272,7 @@ void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, co
     if (n_tiles <= 0) return;
     ProfScope ps("mel_kernel", work, s);
     hipLaunchKernelGGL(mel_kernel, dim3(n_tiles), dim3(256), 0, s, audio, d_off, d_len, d_tile_utt, d_tile_f0, t.hann,
-                       t.twid, t.fb_lo, t.fb_cnt, t.fb_off, t.fb_w, out, t_stride, d_max);
+                       t.twid, t.fb_lo, t.fb_dense, out, t_stride, d_max);
     HIP_CHECK(hipGetLastError());
 }
 
