@@ -69,7 +69,8 @@ def pmc_traffic(kernel, args):
     needs, plus WRITE_SIZE; the passes cannot run inside this process).  Only a summary taken on this exact
     workload counts; anything else reports None."""
     import glob
-    if args.preset != "1.7b" or args.max_tokens != 448 or args.clip_seconds != 30.0:
+    if (args.preset != "1.7b" or args.max_tokens != 448 or args.clip_seconds != 30.0 or args.weights != "bf16"
+            or args.workload == "ragged" or args.audio != "speechlike"):
         return None, None
     short = kernel.split("<")[0].replace("_kernel", "")
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{short}_b{args.batch}.json")), reverse=True):
@@ -113,6 +114,13 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with one GPU, together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--workload", default="transcribe", choices=["transcribe", "mel", "ragged"],
+                    help="transcribe: the headline run, --batch clips of --clip-seconds per GPU.  mel: the log-mel frontend alone on the "
+                         "same clips (device buffers in and out).  ragged: --utterances recordings per GPU with durations U[5, 300] s "
+                         "(seed 4321), cut into pieces of at most 30 s, cost-sharded over the ranks, length-bucketed by the library")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "q4"], help="q4: MLX affine 4-bit group-quantised decoder weights")
+    ap.add_argument("--audio", default="speechlike", choices=["speechlike", "noise"])
+    ap.add_argument("--utterances", type=int, default=256, help="ragged workload: recordings per GPU")
     args = ap.parse_args()
 
     import torch
@@ -133,23 +141,58 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    cfg = make_config(args.preset, max_batch=args.batch)
+    cfg = make_config(args.preset, max_batch=args.batch, weight_format=1 if args.weights == "q4" else 0)
     ck = synth.make_checkpoint(cfg, seed=0)
     model = Qwen3ASRModel.from_checkpoint(cfg, ck, device=local_rank)
-    n = int(args.clip_seconds * 16000)
-    clips = [synth.synth_audio(n, 1234 + rank * args.batch + i) for i in range(args.batch)]
+    if args.workload == "ragged":
+        # Every rank derives the same recording list, keeps its cost-balanced share and numbers the pieces globally.
+        from q3asr.shard import shard_utterances, utterance_cost
+        piece = 480000
+        lens = (np.random.default_rng(4321).uniform(5.0, 300.0, args.utterances * world) * 16000).astype(np.int64)
+        spans = [[(s, min(s + piece, int(L))) for s in range(0, int(L), piece)] for L in lens]
+        costs = [sum(utterance_cost(e - s, args.max_tokens) for s, e in sp) for sp in spans]
+        first_piece = np.concatenate([[0], np.cumsum([len(sp) for sp in spans])])
+        mine = shard_utterances(lens, world, args.max_tokens, costs=costs)[rank]
+        base = [synth.synth_audio(piece, 1234 + i, args.audio) for i in range(8)]
+        clips = [np.tile(base[i % 8], len(spans[i]))[:int(lens[i])] for i in mine]
+        piece_ids = [int(first_piece[i]) + k for i in mine for k in range(len(spans[i]))]
+        bounds = [0]
+        for i in mine:
+            for s, e in spans[i]:
+                bounds.append(bounds[-1] + e - s)
+        offsets = np.asarray(bounds, dtype=np.int64)
+        n_units_total = int(first_piece[-1])
+        what = (f"{args.utterances} recordings per GPU, durations U[5, 300] s (seed 4321), cut every 30 s into "
+                f"{n_units_total} pieces over {world} GPU(s), cost-sharded, groups of {args.batch} length-sorted pieces")
+    else:
+        n = int(args.clip_seconds * 16000)
+        clips = [synth.synth_audio(n, 1234 + rank * args.batch + i, args.audio) for i in range(args.batch)]
+        piece_ids = [rank * args.batch + i for i in range(args.batch)]
+        offsets = np.arange(args.batch + 1, dtype=np.int64) * n
+        n_units_total = world * args.batch
+        what = f"{args.batch} x {args.clip_seconds:g} s synthetic 16 kHz clips per GPU per step"
     dev_audio = torch.from_numpy(np.concatenate(clips)).cuda()
-    offsets = np.arange(args.batch + 1, dtype=np.int64) * n
+    if args.workload == "mel":
+        mel_out = torch.empty((len(piece_ids), 128, 3000), dtype=torch.float32, device="cuda")
+
+    class MelOnly:
+        tokens_total, ms = 0, {}
 
     def step():
+        if args.workload == "mel":
+            frames = model.feature_extractor.process_device(dev_audio.data_ptr(), offsets, mel_out.data_ptr(), 3000)
+            out = MelOnly()
+            out.audio_seconds = float(np.minimum(np.diff(offsets), 480000).sum()) / 16000.0
+            assert int(frames.min()) > 0
+            return out
         out = model.transcribe_batch(None, 16000, max_tokens=args.max_tokens, stop_rules=not args.no_stop_rules,
                                      device_audio=(dev_audio.data_ptr(), offsets))
         if world > 1:
             # the job's one exchange: every rank ends the batch holding every transcript (token ids)
             from q3asr.shard import gather_token_lists
-            local = {rank * args.batch + i: t for i, t in enumerate(out.tokens)}
-            everything = gather_token_lists(local, world * args.batch, dist, device=coll_dev)
-            assert len(everything) == world * args.batch
+            local = dict(zip(piece_ids, out.tokens))
+            everything = gather_token_lists(local, n_units_total, dist, device=coll_dev)
+            assert len(everything) == n_units_total
         return out
 
     def fence():
@@ -179,14 +222,25 @@ def main():
         dt = float(tmax[0])
     audio_s, tokens = float(stats[1]), float(stats[2])
 
+    n_local = len(piece_ids)
+    if args.workload == "mel":
+        metric = "RTFx (audio s per wall s) of the log-mel frontend alone, 30 s clips"
+        label = f"log-mel frontend only (resident fp32 samples -> normalised [128][3000] fp32 log-mel in HBM), {args.audio} audio, {what}"
+    elif args.workload == "ragged":
+        metric = f"RTFx (audio s per wall s) node-wide, {args.preset} {args.weights}, 5-300 s recordings in <= 30 s pieces"
+        label = (f"Qwen3-ASR-{args.preset} {args.weights} full transcribe (reference stop rules, max_tokens {args.max_tokens}), {what}, "
+                 f"audio resident in HBM, seeded random weights of the true shapes")
+    else:
+        metric = "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips"
+        label = (f"Qwen3-ASR-{args.preset} {args.weights} full transcribe (mel+encoder+prefill+greedy decode, reference stop "
+                 f"rules, max_tokens {args.max_tokens}), {what}, audio resident in HBM, seeded random weights of the true shapes")
     if rank == 0 and not prof:
         ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
-        print(json.dumps({"metric": "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips", "value": round(audio_s / dt, 2),
+        print(json.dumps({"metric": metric, "value": round(audio_s / dt, 2),
                           "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": f"latency run without kernel timing, {args.batch} x {args.clip_seconds:g} s clips, "
-                                                 f"max_tokens {args.max_tokens}", "clips_per_gpu": args.batch,
+                          "vs_baseline": None, "dtype": "f32" if args.workload == "mel" else "bf16", "data": "synthetic",
+                          "config": {"workload": "run without kernel timing: " + label, "clips_per_gpu": n_local,
                                      "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}},
                           "roofline": None, "cpu_baseline": None}), flush=True)
     elif rank == 0:
@@ -206,14 +260,12 @@ def main():
         copy_gbs = measured_copy_ceiling(torch)
         read_gbs = round(model.op_read_bandwidth(1 << 32), 1)   # streaming read of 4 GiB: what an HBM-read-bound kernel can reach
         line = {
-            "metric": "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips", "value": round(audio_s / dt, 2),
+            "metric": metric, "value": round(audio_s / dt, 2),
             "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Qwen3-ASR-{args.preset} bf16 full transcribe (mel+encoder+prefill+greedy decode, reference stop "
-                                   f"rules, max_tokens {args.max_tokens}), {args.batch} x {args.clip_seconds:g} s synthetic 16 kHz clips "
-                                   f"per GPU per step, audio resident in HBM, seeded random weights of the true shapes",
-                       "clips_per_gpu": args.batch, "tokens_per_clip": round(tokens / (world * args.batch * args.steps), 1),
+            "dtype": "f32" if args.workload == "mel" else "bf16", "data": "synthetic",
+            "config": {"workload": label,
+                       "clips_per_gpu": n_local, "tokens_per_clip": round(tokens / (n_units_total * args.steps), 1),
                        "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}"},
             "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
                          "frac": round(ach / peak, 4), "peak_measured_copy": copy_gbs, "peak_measured_read": read_gbs, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
@@ -221,7 +273,7 @@ def main():
             "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
                          "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:8]],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "transcribe" and args.weights == "bf16":
             model.close()
             del dev_audio
             line["cpu_baseline"] = cpu_baseline(cfg, ck, clips[0], args.cpu_decode_steps)

@@ -4,14 +4,12 @@
 #include <vector>
 
 constexpr int MEL_NFFT = 400, MEL_HOP = 160, MEL_NMELS = 128, MEL_NBINS = 201, MEL_MAX_FRAMES = 3000;
-constexpr int MEL_FB_WIDTH = 12;  // widest slaney filter at 16 kHz / 400-point FFT spans 9 bins
-constexpr int MEL_TILE_FRAMES = 64;
+constexpr int MEL_TILE_FRAMES = 48;  // frames per kernel tile (three 16-frame MFMA row tiles)
 
 struct MelTables {           // device-resident constants, built once per model
     float* hann = nullptr;   // [208]  periodic Hann, zero beyond n = 200
     float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT
-    int* fb_lo = nullptr;    // [128] first FFT bin of each mel filter
-    float* fb_dense = nullptr;  // [128][MEL_FB_WIDTH] filter weights from fb_lo on, zero after the filter's last bin
+    float* fb_packed = nullptr;  // non-zero filter weights, filter after filter, padded to a multiple of 64
     std::vector<float> host_fb;  // dense [128][201] filterbank (host copy, for inspection / tests)
 };
 
@@ -29,7 +27,7 @@ static inline int mel_frames_out(int64_t n) {
 void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, double ratio, hipStream_t s);
 
 // audio: concatenated 16 kHz samples; d_off[u] / d_len[u]: start and length of utterance u.
-// d_tile_utt / d_tile_f0: one entry per 64-frame tile.  out: [B][128][t_stride] raw log10 mel.
+// d_tile_utt / d_tile_f0: one entry per MEL_TILE_FRAMES-frame tile.  out: [B][128][t_stride] raw log10 mel.
 // d_max: [B] order-preserving encodings of the per-utterance maximum (zeroed by the caller).
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
                 const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work = 0);

@@ -16,6 +16,7 @@
 // launch_mel_normalize for callers that want the reference's exact output tensor.
 #include "mel.h"
 #include "prof.h"
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -25,15 +26,39 @@ namespace {
 
 constexpr int KSTEPS = 26;     // 104 >= 101 folded taps of each parity, 4 per MFMA
 constexpr int NTILES = 7;      // 112 >= 101 bins
-constexpr int SAMPLES = MEL_TILE_FRAMES * MEL_HOP + (MEL_NFFT - MEL_HOP) + 1;  // 10481
+constexpr int MTILES = MEL_TILE_FRAMES / 16;
+constexpr int MEL_THREADS = 64 * (NTILES + 1);  // one transform wave per 16-bin tile + one filterbank / staging wave
+constexpr int SAMPLES = MEL_TILE_FRAMES * MEL_HOP + (MEL_NFFT - MEL_HOP) + 1;  // 7921
+constexpr int SREG = 8032;     // skewed sample image: skew(7920) = 8017
 constexpr int POW_STRIDE = MEL_NBINS;
-constexpr int REGION = MEL_TILE_FRAMES * POW_STRIDE;  // 12864 floats >= skewed sample image (10481 + 133)
+constexpr int POW_N = MEL_TILE_FRAMES * POW_STRIDE + 16;
 constexpr int HANN_N = 208;
+constexpr int MEL_LDS_BYTES = (2 * SREG + HANN_N + 2 * POW_N) * 4;  // two sample images, window, two power spectra: 142 KB
 
-__device__ __forceinline__ int skew(int p) {
-    const int q = p / MEL_HOP;
-    return p + 4 * (q >> 1) + (q & 1);  // frame starts land on distinct banks for the stride-2 fragment reads
+// Support of the slaney filters at 16 kHz / 400-point FFT / 128 bins (AudioPreprocessing.swift:23-126): first FFT bin and
+// number of bins of every filter.  Fixed by the reference's constants; mel_tables_create checks the computed filterbank
+// against it.  Knowing it at compile time turns the filterbank phase into straight-line code with immediate LDS offsets.
+constexpr unsigned char FB_LO[MEL_NMELS] = {
+    1, 1, 2, 2, 3, 3, 4, 5, 5, 6, 6, 7, 8, 8, 9, 9, 10, 10, 11, 12, 12, 13, 13, 14, 15, 15, 16, 16, 17, 17, 18, 19,
+    19, 20, 20, 21, 22, 22, 23, 23, 24, 24, 25, 26, 26, 27, 28, 28, 29, 30, 30, 31, 32, 32, 33, 34, 35, 36, 37, 37, 38, 39, 40, 41,
+    42, 43, 44, 45, 46, 48, 49, 50, 51, 52, 54, 55, 56, 58, 59, 60, 62, 63, 65, 66, 68, 70, 71, 73, 75, 77, 79, 80, 82, 84, 86, 89,
+    91, 93, 95, 98, 100, 102, 105, 107, 110, 113, 115, 118, 121, 124, 127, 130, 133, 136, 140, 143, 147, 150, 154, 158, 161, 165, 169, 174, 178, 182, 187, 191};
+constexpr unsigned char FB_W[MEL_NMELS] = {
+    1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1,
+    1, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 2, 1, 1, 2, 1, 1, 2, 1, 1, 2, 2, 2, 2, 1, 1, 2, 2, 2, 2, 2,
+    2, 2, 2, 3, 3, 2, 2, 2, 3, 3, 2, 3, 3, 2, 3, 3, 3, 3, 3, 4, 3, 3, 4, 4, 4, 3, 3, 4, 4, 5, 5, 4,
+    4, 5, 5, 4, 5, 5, 5, 6, 5, 5, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 8, 7, 7, 8, 9, 9, 8, 9, 9, 9, 9};
+constexpr int fb_offset(int m) {  // position of filter m's first weight in the packed weight list
+    int o = 0;
+    for (int i = 0; i < m; ++i) o += FB_W[i];
+    return o;
 }
+constexpr int FB_TOTAL = fb_offset(MEL_NMELS);       // 394
+constexpr int FB_REGS = (FB_TOTAL + 63) / 64;        // packed weights, one per lane per register
+
+__device__ __forceinline__ int frame_skew(int q) { return 4 * (q >> 1) + (q & 1); }
+// Frame starts (multiples of 160 samples) land on distinct banks for the stride-2 fragment reads.
+__device__ __forceinline__ int skew(int p) { return p + frame_skew(p / MEL_HOP); }
 
 __device__ __forceinline__ unsigned enc_max(float f) {
     const unsigned b = __float_as_uint(f);
@@ -43,114 +68,277 @@ __device__ __forceinline__ float dec_max(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audio, const int64_t* __restrict__ d_off,
-                                                  const int64_t* __restrict__ d_len, const int* __restrict__ tile_utt,
-                                                  const int* __restrict__ tile_f0, const float* __restrict__ hann_g,
-                                                  const float* __restrict__ twid, const int* __restrict__ fb_lo,
-                                                  const float* __restrict__ fb_dense, float* __restrict__ out, int t_stride,
-                                                  unsigned* __restrict__ d_max) {
-    __shared__ __attribute__((aligned(16))) float sm[REGION + HANN_N + 4];
-    float* hann = sm + REGION;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int u = tile_utt[blockIdx.x], f0 = tile_f0[blockIdx.x];
-    const int64_t n = d_len[u];
-    const float* x = audio + d_off[u];
-    const int frames_total = (int)(n / MEL_HOP) + 1;
-    const int frames_out = min(frames_total - 1, MEL_MAX_FRAMES);
+struct TileInfo {
+    const float* x;  // utterance samples
+    int64_t n;       // utterance length
+    int u, f0;
+};
 
-    // ---- stage samples (reflect pad of 200: AudioPreprocessing.swift:134-154) ----
-    const int64_t P0 = (int64_t)f0 * MEL_HOP;
-    for (int p = tid; p < SAMPLES; p += 256) {
-        const int64_t P = P0 + p;
-        float v = 0.f;
-        if (n > 0 && P < n + MEL_NFFT) {
-            int64_t idx;
-            if (P < 200) idx = min((int64_t)200 - P, n - 1);
-            else if (P < 200 + n) idx = P - 200;
-            else idx = n - 2 - (P - 200 - n);
-            v = x[max(idx, (int64_t)0)];
+__device__ __forceinline__ TileInfo tile_info(const float* audio, const int64_t* d_off, const int64_t* d_len, const int* tile_utt,
+                                              const int* tile_f0, int t) {
+    TileInfo ti;
+    ti.u = tile_utt[t];
+    ti.f0 = tile_f0[t];
+    ti.n = d_len[ti.u];
+    ti.x = audio + d_off[ti.u];
+    return ti;
+}
+
+__device__ __forceinline__ bool tile_is_interior(const TileInfo& ti) {  // no padding inside the tile
+    const int64_t P0 = (int64_t)ti.f0 * MEL_HOP;
+    return P0 >= 200 && P0 + SAMPLES <= ti.n + 200;
+}
+
+// Interior tile: loads this thread's share (samples id, id + STRIDE, ...) into registers; all loads are issued before
+// anything waits on them, and write_tile stores them into a skewed LDS image later.
+template <int N, int STRIDE, int I0>
+__device__ __forceinline__ void fetch_tile(const TileInfo& ti, float (&sv)[N], int id) {
+    const float* xs = ti.x + ((int64_t)ti.f0 * MEL_HOP - 200);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int p = id + (I0 + i) * STRIDE;
+        sv[i] = ((I0 + i + 1) * STRIDE <= SAMPLES || p < SAMPLES) ? xs[p] : 0.f;
+    }
+}
+
+template <int N, int STRIDE, int I0>
+__device__ __forceinline__ void write_tile(const float (&sv)[N], float* dst, int id) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int p = id + (I0 + i) * STRIDE;
+        if ((I0 + i + 1) * STRIDE <= SAMPLES || p < SAMPLES) dst[skew(p)] = sv[i];
+    }
+}
+
+// Tile that touches the reflect padding of 200 samples or the end of the utterance (AudioPreprocessing.swift:134-154):
+// staged directly, BATCH loads at a time.
+template <int BATCH>
+__device__ __forceinline__ void stage_edge_tile(const TileInfo& ti, float* dst, int id, int stride) {
+    const int64_t P0 = (int64_t)ti.f0 * MEL_HOP, n = ti.n;
+    for (int p0 = id; p0 < SAMPLES; p0 += BATCH * stride) {
+        float v[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int64_t P = P0 + p0 + i * stride;
+            int64_t idx = P < 200 ? 200 - P : (P < 200 + n ? P - 200 : 2 * n + 198 - P);
+            idx = max(min(idx, n - 1), (int64_t)0);
+            v[i] = (n > 0 && P < n + MEL_NFFT) ? ti.x[idx] : 0.f;
         }
-        sm[skew(p)] = v;
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int p = p0 + i * stride;
+            if (p < SAMPLES) dst[skew(p)] = v[i];
+        }
     }
+}
+
+// Filter M applied to the power spectrum row of this lane's frame; weights come from the lane-packed registers.
+template <int M>
+__device__ __forceinline__ float mel_filter(const float* pw, const float (&fbv)[FB_REGS]) {
+    constexpr int lo = FB_LO[M], w = FB_W[M], off = fb_offset(M);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < w; ++c) {
+        const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fbv[(off + c) >> 6]), (off + c) & 63));
+        sum = fmaf(pw[lo + c], wt, sum);
+    }
+    return sum;
+}
+
+constexpr int MEL_GROUP = 16;  // filters evaluated together: straight-line code, one predicated burst of stores
+
+template <int M0, int J>
+__device__ __forceinline__ void mel_values(const float* pw, const float (&fbv)[FB_REGS], float (&v)[MEL_GROUP]) {
+    if constexpr (J < MEL_GROUP) {
+        // log10 of the clamped filter output (AudioPreprocessing.swift:232-255).  The hardware log2 is accurate to 1 ulp
+        // and the argument is never denormal, so the plain product is within 2e-6 of the correctly rounded value.
+        v[J] = __log2f(fmaxf(mel_filter<M0 + J>(pw, fbv), 1e-10f)) * 0.30102999566398120f;
+        mel_values<M0, J + 1>(pw, fbv, v);
+    }
+}
+
+struct MelOut {
+    float* out;     // this lane's column of the utterance's [128][t_stride] block
+    int t_stride;
+    bool store;
+    float vmax;
+};
+
+template <int M0, int M1>
+__device__ __forceinline__ void mel_rows(const float* pw, const float (&fbv)[FB_REGS], MelOut& o) {
+    if constexpr (M0 < M1) {
+        float v[MEL_GROUP];
+        mel_values<M0, 0>(pw, fbv, v);
+#pragma unroll
+        for (int j = 0; j < MEL_GROUP; ++j) o.vmax = fmaxf(o.vmax, v[j]);
+        if (o.store) {
+#pragma unroll
+            for (int j = 0; j < MEL_GROUP; ++j) o.out[(int64_t)(M0 + j) * o.t_stride] = v[j];
+        }
+        mel_rows<M0 + MEL_GROUP, M1>(pw, fbv, o);
+    }
+}
+
+// Persistent workgroups: each takes tiles blockIdx.x, blockIdx.x + gridDim.x, ... of 48 frames.  Waves 0-6 transform: wave w
+// owns bins 16w .. 16w+15 of all four products and keeps their twiddles (4 x 26 fragments) in registers for the whole kernel,
+// so the MFMA loop reads only LDS.  Wave 7 meanwhile turns the previous tile's power spectrum into log-mel rows and stages the
+// next tile's samples; sample image and power spectrum are double buffered and one barrier per tile hands them over.
+__global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const float* __restrict__ audio, const int64_t* __restrict__ d_off,
+                                                          const int64_t* __restrict__ d_len, const int* __restrict__ tile_utt,
+                                                          const int* __restrict__ tile_f0, int n_tiles,
+                                                          const float* __restrict__ hann_g, const float* __restrict__ twid,
+                                                          const float* __restrict__ fb_packed, float* __restrict__ out,
+                                                          int t_stride, unsigned* __restrict__ d_max) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hann = sm + 2 * SREG;
+    float* pwr = hann + HANN_N;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
     if (tid < HANN_N) hann[tid] = hann_g[tid];
-    __syncthreads();
-
-    // ---- folded DFT on the fp32 MFMA: wave w owns frames 16w .. 16w+15 ----
-    f32x4 acc[4][NTILES];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < NTILES; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int li = lane & 15, lg = lane >> 4;
-    const int s0 = (16 * wave + li) * MEL_HOP;
-    const float* tw = twid + lane;
-    for (int s = 0; s < KSTEPS; ++s) {
-        const int e = 2 * (4 * s + lg);
-        const float xa = sm[skew(s0 + e)], xb = sm[skew(s0 + MEL_NFFT - e)];
-        const float xc = sm[skew(s0 + e + 1)], xd = sm[skew(s0 + MEL_NFFT - 1 - e)];
-        const float he = hann[e], ho = hann[e + 1];
-        float av[4];
-        av[0] = he * (xa + xb);  // even samples, cosine part
-        av[1] = ho * (xc + xd);  // odd samples, cosine part
-        av[2] = he * (xa - xb);  // even samples, sine part
-        av[3] = ho * (xc - xd);  // odd samples, sine part
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-            for (int nt = 0; nt < NTILES; ++nt) {
-                const float b = tw[((s * 4 + pr) * NTILES + nt) * 64];
-                acc[pr][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr], b, acc[pr][nt], 0, 0, 0);
-            }
+    int t = blockIdx.x;
+    if (t < n_tiles) {
+        stage_edge_tile<4>(tile_info(audio, d_off, d_len, tile_utt, tile_f0, t), sm, tid, MEL_THREADS);
     }
-    __syncthreads();  // every wave is done with the sample image; reuse it for the power spectrum
 
-    // ---- power spectrum |X[k]|^2 (AudioPreprocessing.swift:207): bins k and 200-k from the same four sums ----
+    if (wave < NTILES) {
+        // ================= transform waves =================
+        const int li = lane & 15, lg = lane >> 4;
+        float tw[4][KSTEPS];
 #pragma unroll
-    for (int nt = 0; nt < NTILES; ++nt) {
-        const int k = 16 * nt + li;
-        if (k <= 100) {
+        for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int fr = 16 * wave + 4 * lg + r;
-                const float ce = acc[0][nt][r], co = acc[1][nt][r], se = acc[2][nt][r], so = acc[3][nt][r];
-                const float re = ce + co, im = se + so;
-                sm[fr * POW_STRIDE + k] = re * re + im * im;
-                if (k < 100) {
-                    const float re2 = ce - co, im2 = se - so;
-                    sm[fr * POW_STRIDE + 200 - k] = re2 * re2 + im2 * im2;
+            for (int pr = 0; pr < 4; ++pr) tw[pr][s] = twid[((s * 4 + pr) * NTILES + wave) * 64 + lane];
+        const float* hw = hann + 2 * lg;
+        const int k = 16 * wave + li;
+        int buf = 0;
+        for (; t < n_tiles; t += gridDim.x) {
+            __syncthreads();  // this tile's samples are staged; the power buffer written below has been consumed
+            const float* smp = sm + buf * SREG;
+            float* pw = pwr + buf * POW_N;
+#pragma unroll 1
+            for (int mt = 0; mt < MTILES; ++mt) {
+                const int fr = 16 * mt + li;
+                const int s0 = fr * MEL_HOP;
+                // tap e of this frame sits at s0 + e + frame_skew(fr + e / 160); e / 160 is fixed per step except at step 10
+                const float* pa0 = smp + s0 + frame_skew(fr) + 2 * lg;                 // taps e < 160
+                const float* pa1 = smp + s0 + frame_skew(fr + 1) + 2 * lg;             // taps e >= 160
+                const float* pb2 = smp + s0 + frame_skew(fr + 2) + MEL_NFFT - 2 * lg;  // mirrored taps 400 - e >= 320
+                const float* pb1 = smp + s0 + frame_skew(fr + 1) + MEL_NFFT - 2 * lg;  // mirrored taps 400 - e < 320
+                const float* pb_edge = lg == 0 ? pb2 : pb1;                            // step 10: e = 80 mirrors to 320, e > 80 below it
+                f32x4 acc[4];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) acc[pr] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // operands of step s + 1 are read from LDS before the MFMAs of step s are issued
+                float nx[6];
+                auto fetch = [&](int s) {
+                    const float* pa = s < 20 ? pa0 : pa1;
+                    const float* pb = s < 10 ? pb2 : (s == 10 ? pb_edge : pb1);
+                    const float* pd = s < 10 ? pb2 : pb1;
+                    nx[0] = pa[8 * s], nx[1] = pa[8 * s + 1];
+                    nx[2] = pb[-8 * s], nx[3] = pd[-8 * s - 1];
+                    nx[4] = hw[8 * s], nx[5] = hw[8 * s + 1];
+                };
+                fetch(0);
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    const float xa = nx[0], xc = nx[1], xb = nx[2], xd = nx[3], he = nx[4], ho = nx[5];
+                    if (s + 1 < KSTEPS) fetch(s + 1);
+                    __builtin_amdgcn_sched_barrier(0);  // keeps those reads ahead of this step's arithmetic
+                    float av[4];
+                    av[0] = he * (xa + xb);  // even samples, cosine part
+                    av[1] = ho * (xc + xd);  // odd samples, cosine part
+                    av[2] = he * (xa - xb);  // even samples, sine part
+                    av[3] = ho * (xc - xd);  // odd samples, sine part
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr)
+                        acc[pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr], tw[pr][s], acc[pr], 0, 0, 0);
+                }
+                // power spectrum |X[k]|^2 (AudioPreprocessing.swift:207): bins k and 200-k from the same four sums
+                if (k <= 100) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * mt + 4 * lg + r;
+                        const float ce = acc[0][r], co = acc[1][r], se = acc[2][r], so = acc[3][r];
+                        const float re = ce + co, im = se + so;
+                        pw[row * POW_STRIDE + k] = re * re + im * im;
+                        if (k < 100) {
+                            const float re2 = ce - co, im2 = se - so;
+                            pw[row * POW_STRIDE + 200 - k] = re2 * re2 + im2 * im2;
+                        }
+                    }
                 }
             }
+            buf ^= 1;
+        }
+        __syncthreads();  // releases the last power spectrum to the filterbank wave
+    } else {
+        // ================= filterbank / staging wave =================
+        float fbv[FB_REGS];
+#pragma unroll
+        for (int i = 0; i < FB_REGS; ++i) fbv[i] = fb_packed[i * 64 + lane];
+        // Per tile: filters 0-63 of the previous tile, then filters 64-127; the next tile's samples travel through
+        // registers in two halves, each fetched before one filterbank half and written to the other image after it.
+        constexpr int N1 = ((SAMPLES + 63) / 64 + 1) / 2;
+        float sv[N1];
+        MelOut o;
+        const float* pw_row = nullptr;
+        TileInfo cur, next;
+        bool live = false;
+        auto begin_tile = [&](int tile, const float* pw_tile) {
+            cur = tile_info(audio, d_off, d_len, tile_utt, tile_f0, tile);
+            const int frames_total = (int)(cur.n / MEL_HOP) + 1;
+            const int frames_out = min(frames_total - 1, MEL_MAX_FRAMES);
+            const int frame = cur.f0 + lane;
+            const bool in_tile = lane < MEL_TILE_FRAMES;   // lanes beyond the tile do nothing
+            o.out = out + (int64_t)cur.u * MEL_NMELS * t_stride + frame;
+            o.t_stride = t_stride;
+            o.store = in_tile && frame < frames_out;
+            o.vmax = -INFINITY;
+            // running maximum over every frame the reference computes, the dropped last one included (:269-270)
+            live = in_tile && frame < frames_total;
+            pw_row = pw_tile + min(lane, MEL_TILE_FRAMES - 1) * POW_STRIDE;
+        };
+        auto end_tile = [&]() {
+            const float vmax = wave_max(live ? o.vmax : -INFINITY);
+            if (lane == 0 && vmax > -INFINITY) atomicMax(d_max + cur.u, enc_max(vmax));
+        };
+        int buf = 0, prev = -1;
+        for (; t < n_tiles; t += gridDim.x) {
+            __syncthreads();
+            const int tn = t + gridDim.x;
+            float* dst = sm + (buf ^ 1) * SREG;
+            bool interior = false;
+            if (tn < n_tiles) {
+                next = tile_info(audio, d_off, d_len, tile_utt, tile_f0, tn);
+                interior = tile_is_interior(next);
+            }
+            if (interior) fetch_tile<N1, 64, 0>(next, sv, lane);
+            if (prev >= 0) {
+                begin_tile(prev, pwr + (buf ^ 1) * POW_N);
+                mel_rows<0, MEL_NMELS / 2>(pw_row, fbv, o);
+            }
+            if (interior) {
+                write_tile<N1, 64, 0>(sv, dst, lane);
+                fetch_tile<N1, 64, N1>(next, sv, lane);
+            }
+            if (prev >= 0) {
+                mel_rows<MEL_NMELS / 2, MEL_NMELS>(pw_row, fbv, o);
+                end_tile();
+            }
+            if (interior) write_tile<N1, 64, N1>(sv, dst, lane);
+            else if (tn < n_tiles) stage_edge_tile<16>(next, dst, lane, 64);
+            prev = t;
+            buf ^= 1;
+        }
+        __syncthreads();
+        if (prev >= 0) {
+            begin_tile(prev, pwr + (buf ^ 1) * POW_N);
+            mel_rows<0, MEL_NMELS>(pw_row, fbv, o);
+            end_tile();
         }
     }
-    __syncthreads();
 
-    // ---- sparse slaney filterbank + log10 (AudioPreprocessing.swift:232-255), running max (:269-270) ----
-    const int f = tid & 63, mg = tid >> 6;
-    const int frame = f0 + f;
-    const float* pw = sm + f * POW_STRIDE;
-    float vmax = -INFINITY;
-    // Every filter is stored MEL_FB_WIDTH wide (zero weights after its last bin), so the table reads are
-    // wave-uniform loads of fixed size that do not depend on one another; the zero terms leave the sum unchanged.
-#pragma unroll 4
-    for (int i = 0; i < MEL_NMELS / 4; ++i) {
-        const int m = mg * (MEL_NMELS / 4) + i;
-        const int lo = fb_lo[m];
-        const float* w = fb_dense + m * MEL_FB_WIDTH;
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < MEL_FB_WIDTH; ++c) sum = fmaf(pw[lo + c], w[c], sum);
-        const float v = log10f(fmaxf(sum, 1e-10f));
-        if (frame < frames_total) vmax = fmaxf(vmax, v);
-        if (frame < frames_out) out[((int64_t)u * MEL_NMELS + m) * t_stride + frame] = v;
-    }
-    vmax = wave_max(vmax);
-    __shared__ float wmax[4];
-    if (lane == 0) wmax[wave] = vmax;
-    __syncthreads();
-    if (tid == 0) {
-        const float b = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (b > -INFINITY) atomicMax(d_max + u, enc_max(b));
-    }
 }
 
 __global__ void mel_normalize_kernel(float* __restrict__ out, int t_stride, const int* __restrict__ frames_out,
@@ -238,26 +426,20 @@ void mel_tables_create(MelTables& t) {
     t.twid = upload(tw);
 
     t.host_fb = build_filterbank();
-    std::vector<int> lo(MEL_NMELS);
-    std::vector<float> dense((size_t)MEL_NMELS * MEL_FB_WIDTH, 0.f);
-    for (int m = 0; m < MEL_NMELS; ++m) {
-        int first = -1, last = -1;
-        for (int b = 0; b < MEL_NBINS; ++b)
-            if (t.host_fb[(size_t)m * MEL_NBINS + b] != 0.f) {
-                if (first < 0) first = b;
-                last = b;
-            }
-        if (first < 0) first = 0, last = -1;
-        Q3_REQUIRE(last - first + 1 <= MEL_FB_WIDTH, "mel: a filter spans more FFT bins than the kernel's table width");
-        lo[m] = first;
-        for (int b = first; b <= last; ++b) dense[(size_t)m * MEL_FB_WIDTH + (b - first)] = t.host_fb[(size_t)m * MEL_NBINS + b];
-    }
-    t.fb_lo = upload(lo);
-    t.fb_dense = upload(dense);
+    // The kernel's compile-time filter supports must cover every weight that matters; anything outside them has to be
+    // rounding dust of the triangle edges (none with the libm this was built against).
+    std::vector<float> packed((size_t)FB_REGS * 64, 0.f);
+    for (int m = 0; m < MEL_NMELS; ++m)
+        for (int b = 0; b < MEL_NBINS; ++b) {
+            const float w = t.host_fb[(size_t)m * MEL_NBINS + b];
+            if (b >= FB_LO[m] && b < FB_LO[m] + FB_W[m]) packed[fb_offset(m) + (b - FB_LO[m])] = w;
+            else Q3_REQUIRE(fabsf(w) < 1e-9f, "mel: the filterbank has a weight outside the kernel's filter supports");
+        }
+    t.fb_packed = upload(packed);
 }
 
 void mel_tables_destroy(MelTables& t) {
-    (void)hipFree(t.hann); (void)hipFree(t.twid); (void)hipFree(t.fb_lo); (void)hipFree(t.fb_dense);
+    (void)hipFree(t.hann); (void)hipFree(t.twid); (void)hipFree(t.fb_packed);
     t = MelTables();
 }
 
@@ -270,9 +452,17 @@ void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, d
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
                 const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work) {
     if (n_tiles <= 0) return;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES));
+    }
     ProfScope ps("mel_kernel", work, s);
-    hipLaunchKernelGGL(mel_kernel, dim3(n_tiles), dim3(256), 0, s, audio, d_off, d_len, d_tile_utt, d_tile_f0, t.hann,
-                       t.twid, t.fb_lo, t.fb_dense, out, t_stride, d_max);
+    // one workgroup fits per CU (142 KB of LDS); each loops over its share of the tiles
+    hipLaunchKernelGGL(mel_kernel, dim3(std::min(n_tiles, cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,
+                       d_tile_utt, d_tile_f0, n_tiles, t.hann, t.twid, t.fb_packed, out, t_stride, d_max);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -60,8 +60,9 @@ struct MelRun {
 };
 
 // src_off / src_len: position of every utterance in `audio` (input sample rate).
+// dst: optional device buffer [b][128][t_stride] that receives the raw log-mel instead of workspace memory.
 MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>& src_off, const std::vector<int64_t>& src_len,
-               int sample_rate, int t_stride) {
+               int sample_rate, int t_stride, float* dst = nullptr) {
     const int b = (int)src_off.size();
     MelRun r;
     r.n16.resize(b);
@@ -111,7 +112,7 @@ MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>
     Q3_REQUIRE(r.t_stride >= tmax, "mel: t_stride is smaller than the longest utterance's frame count");
     double mel_bytes = 0;  // algorithmic traffic: samples in + returned frames out
     for (int u = 0; u < b; ++u) mel_bytes += 4.0 * (double)r.n16[u] + 4.0 * MEL_NMELS * (double)r.frames[u];
-    r.raw = c.get<float>((size_t)b * MEL_NMELS * r.t_stride);
+    r.raw = dst ? dst : c.get<float>((size_t)b * MEL_NMELS * r.t_stride);
     r.dmax = c.get<unsigned>(b);
     HIP_CHECK(hipMemsetAsync(r.dmax, 0, (size_t)b * 4, c.s));
     r.d_frames = c.up(r.frames);
@@ -285,10 +286,11 @@ void model_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n
         len[u] = offsets[u + 1] - offsets[u];
         Q3_REQUIRE(len[u] >= 0, "mel: offsets must be non-decreasing");
     }
-    MelRun r = run_mel(c, audio, audio_space, off, len, sample_rate, t_stride);
+    Q3_REQUIRE(t_stride > 0, "mel: t_stride must be positive");
+    const bool direct = out_space == Q3ASR_DEVICE;   // a device caller's buffer is written by the kernels themselves
+    MelRun r = run_mel(c, audio, audio_space, off, len, sample_rate, t_stride, direct ? mel_out : nullptr);
     launch_mel_normalize(r.raw, n_utt, r.t_stride, r.d_frames, r.dmax, c.s);
-    const size_t bytes = (size_t)n_utt * MEL_NMELS * r.t_stride * 4;
-    HIP_CHECK(hipMemcpyAsync(mel_out, r.raw, bytes, out_space == Q3ASR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c.s));
+    if (!direct) HIP_CHECK(hipMemcpyAsync(mel_out, r.raw, (size_t)n_utt * MEL_NMELS * r.t_stride * 4, hipMemcpyDeviceToHost, c.s));
     HIP_CHECK(hipStreamSynchronize(c.s));
     for (int u = 0; u < n_utt; ++u) n_frames[u] = r.frames[u];
 }

@@ -65,6 +65,17 @@ class WhisperFeatureExtractor:
                                             _lib.HOST, out.ctypes.data, t_stride, _ptr(nfr, ctypes.c_int32), _lib.HOST))
         return [np.ascontiguousarray(out[i, :, :nfr[i]]) for i in range(len(audios))]
 
+    def process_device(self, audio_ptr, offsets, out_ptr, t_stride=3000, sample_rate=16000):
+        """Same stage on buffers that already live in HBM: `audio_ptr` = device address of the concatenated fp32
+        samples, `out_ptr` = device address of an [n][128][t_stride] fp32 buffer the log-mel is written into.
+        Returns the frame count of every utterance."""
+        m = self._m
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        nfr = np.zeros(len(off) - 1, dtype=np.int32)
+        _lib.check(m._lib, m._lib.q3asr_mel(m._h, audio_ptr, _ptr(off, ctypes.c_int64), len(off) - 1, int(sample_rate),
+                                            _lib.DEVICE, out_ptr, int(t_stride), _ptr(nfr, ctypes.c_int32), _lib.DEVICE))
+        return nfr
+
 
 class Qwen3AudioEncoder:
     """AudioEncoder.swift:173-502."""

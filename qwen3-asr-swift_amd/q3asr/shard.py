@@ -15,11 +15,12 @@ def utterance_cost(n_samples_16k, max_tokens=448):
     return (frames // 100) * 13 + (7 if frames % 100 else 0) + 15 + max_tokens
 
 
-def shard_utterances(lengths_16k, world, max_tokens=448):
+def shard_utterances(lengths_16k, world, max_tokens=448, costs=None):
     """Greedy longest-first assignment of utterances to ranks by cost.  Returns a list (one entry per
     rank) of utterance indices, each sorted by decreasing length so that the rank's internal groups
-    are length-bucketed."""
-    costs = [utterance_cost(n, max_tokens) for n in lengths_16k]
+    are length-bucketed.  `costs` overrides the per-utterance cost (a recording that will be cut into
+    several pieces costs the sum of its pieces)."""
+    costs = [utterance_cost(n, max_tokens) for n in lengths_16k] if costs is None else list(costs)
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
     load = [0] * world
     shards = [[] for _ in range(world)]

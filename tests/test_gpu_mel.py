@@ -88,3 +88,43 @@ def test_mel_test_wav_24k_resample(tiny_model):
     assert rate == 24000 and len(audio) == 480000
     got = tiny_model[0].feature_extractor.process(audio, rate)
     assert _check(got, audio, rate, tiny_model[0]).shape == (128, 2000)
+
+
+def _hip_runtime():
+    """The HIP runtime the library itself is linked against (already mapped into this process)."""
+    import ctypes
+    with open("/proc/self/maps") as f:
+        paths = {line.split()[-1] for line in f if "libamdhip64" in line and "/torch/" not in line}
+    assert paths, "libq3asr is loaded, so its HIP runtime must be mapped"
+    hip = ctypes.CDLL(sorted(paths)[0])
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    return hip
+
+
+def test_mel_device_buffers_match_host_path(tiny_model):
+    """The stage on buffers that already live in HBM (what a batching host hands over) writes the caller's device
+    buffer directly; it must give exactly what the host-buffer call returns, ragged lengths included."""
+    import ctypes
+    m = tiny_model[0]
+    hip = _hip_runtime()
+    lens = [480000, 16000 * 7 + 13, 160 * 250, 333]
+    audios = [synth.synth_audio(n, 300 + i) for i, n in enumerate(lens)]
+    want = m.feature_extractor.process_batch(audios, 16000)
+    cat = np.concatenate(audios)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    got = np.full((len(lens), 128, 3000), np.nan, dtype=np.float32)
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_in), cat.nbytes) == 0 and hip.hipMalloc(ctypes.byref(d_out), got.nbytes) == 0
+    try:
+        assert hip.hipMemcpy(d_in, cat.ctypes.data, cat.nbytes, 1) == 0          # host to device
+        assert hip.hipMemcpy(d_out, got.ctypes.data, got.nbytes, 1) == 0
+        frames = m.feature_extractor.process_device(d_in.value, off, d_out.value, 3000)
+        assert hip.hipMemcpy(got.ctypes.data, d_out, got.nbytes, 2) == 0          # device to host
+    finally:
+        hip.hipFree(d_in)
+        hip.hipFree(d_out)
+    for i, w in enumerate(want):
+        assert frames[i] == w.shape[1]
+        assert np.array_equal(got[i, :, :frames[i]], w)
