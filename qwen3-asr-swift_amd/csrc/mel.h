@@ -7,8 +7,7 @@ constexpr int MEL_NFFT = 400, MEL_HOP = 160, MEL_NMELS = 128, MEL_NBINS = 201, M
 constexpr int MEL_TILE_FRAMES = 48;  // frames per kernel tile (three 16-frame MFMA row tiles)
 
 struct MelTables {           // device-resident constants, built once per model
-    float* hann = nullptr;   // [208]  periodic Hann, zero beyond n = 200
-    float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT
+    float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT, Hann window included
     float* fb_packed = nullptr;  // non-zero filter weights, filter after filter, padded to a multiple of 64
     std::vector<float> host_fb;  // dense [128][201] filterbank (host copy, for inspection / tests)
 };

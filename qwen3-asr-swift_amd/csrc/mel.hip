@@ -1,19 +1,20 @@
 // Log-mel frontend for gfx950.
 //
 // Restates WhisperFeatureExtractor (reference: Sources/Qwen3ASR/AudioPreprocessing.swift:131-324).
-// One workgroup = 64 frames of one utterance.  The 10 480 samples those frames cover are staged
-// once in LDS (coalesced, reflect padding resolved on load).  Because the frame is real, the
-// 400-point DFT folds to Re X[k] = sum_{n<=200} h[n](x[n] + x[400-n]) cos(2 pi k n / 400) and
+// Work is cut into tiles of 48 frames of one utterance; persistent workgroups (one per CU) loop over the tiles.
+// The 7 920 samples a tile covers are staged once in LDS (coalesced, reflect padding resolved on load).  Because the
+// frame is real, the 400-point DFT folds to Re X[k] = sum_{n<=200} h[n](x[n] + x[400-n]) cos(2 pi k n / 400) and
 // Im X[k] = -sum h[n](x[n] - x[400-n]) sin(...); splitting those sums into even and odd n gives four
 // [frames x 101] x [101 x 101] real products (Ce, Co, Se, So over bins 0..100) from which bin k is
 // (Ce + Co, Se + So) and bin 200 - k is (Ce - Co, Se - So): a quarter of the direct DFT's multiplies,
-// evaluated on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, an fp32 fma chain).  The difference form
-// loses accuracy only where bin 200 - k is far weaker than bin k: relative error ~6e-8 * |X[k]| / |X[200-k]|,
-// i.e. < 1e-5 of log-mel for a 60 dB spread between the halves of the spectrum.  Power, the sparse
-// slaney filterbank, log10 and a per-utterance running maximum (wave reduction + one atomic per
-// workgroup) follow without leaving the CU.  Output is the raw log10 mel; the max-8 clamp and
-// (x+4)/4 scale need the utterance-wide maximum and are applied by the consumer (conv1) or by
-// launch_mel_normalize for callers that want the reference's exact output tensor.
+// evaluated on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, an fp32 fma chain) with the Hann window folded into the
+// twiddle tables.  The difference form loses accuracy only where bin 200 - k is far weaker than bin k: relative error
+// ~6e-8 * |X[k]| / |X[200-k]|, i.e. < 1e-5 of log-mel for a 60 dB spread between the halves of the spectrum.
+// Seven waves transform (one 16-bin tile each, twiddles resident in registers); an eighth wave applies the slaney
+// filterbank, log10 and the per-utterance running maximum (wave reduction + one atomic per tile) to the previous
+// tile's power spectrum and stages the next tile's samples, so neither phase waits for the other.  Output is the raw
+// log10 mel; the max-8 clamp and (x+4)/4 scale need the utterance-wide maximum and are applied by the consumer
+// (conv1) or by launch_mel_normalize for callers that want the reference's exact output tensor.
 #include "mel.h"
 #include "prof.h"
 #include <algorithm>
@@ -21,6 +22,7 @@
 #include <vector>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 namespace {
 
@@ -33,7 +35,7 @@ constexpr int SREG = 8032;     // skewed sample image: skew(7920) = 8017
 constexpr int POW_STRIDE = MEL_NBINS;
 constexpr int POW_N = MEL_TILE_FRAMES * POW_STRIDE + 16;
 constexpr int HANN_N = 208;
-constexpr int MEL_LDS_BYTES = (2 * SREG + HANN_N + 2 * POW_N) * 4;  // two sample images, window, two power spectra: 142 KB
+constexpr int MEL_LDS_BYTES = (2 * SREG + 2 * POW_N) * 4;  // two sample images, two power spectra: 142 KB
 
 // Support of the slaney filters at 16 kHz / 400-point FFT / 128 bins (AudioPreprocessing.swift:23-126): first FFT bin and
 // number of bins of every filter.  Fixed by the reference's constants; mel_tables_create checks the computed filterbank
@@ -186,16 +188,14 @@ __device__ __forceinline__ void mel_rows(const float* pw, const float (&fbv)[FB_
 __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const float* __restrict__ audio, const int64_t* __restrict__ d_off,
                                                           const int64_t* __restrict__ d_len, const int* __restrict__ tile_utt,
                                                           const int* __restrict__ tile_f0, int n_tiles,
-                                                          const float* __restrict__ hann_g, const float* __restrict__ twid,
+                                                          const float* __restrict__ twid,
                                                           const float* __restrict__ fb_packed, float* __restrict__ out,
                                                           int t_stride, unsigned* __restrict__ d_max) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* hann = sm + 2 * SREG;
-    float* pwr = hann + HANN_N;
+    float* pwr = sm + 2 * SREG;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    if (tid < HANN_N) hann[tid] = hann_g[tid];
     int t = blockIdx.x;
     if (t < n_tiles) {
         stage_edge_tile<4>(tile_info(audio, d_off, d_len, tile_utt, tile_f0, t), sm, tid, MEL_THREADS);
@@ -209,52 +209,40 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const float* __restric
         for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) tw[pr][s] = twid[((s * 4 + pr) * NTILES + wave) * 64 + lane];
-        const float* hw = hann + 2 * lg;
         const int k = 16 * wave + li;
         int buf = 0;
         for (; t < n_tiles; t += gridDim.x) {
             __syncthreads();  // this tile's samples are staged; the power buffer written below has been consumed
-            const float* smp = sm + buf * SREG;
             float* pw = pwr + buf * POW_N;
-#pragma unroll 1
-            for (int mt = 0; mt < MTILES; ++mt) {
-                const int fr = 16 * mt + li;
-                const int s0 = fr * MEL_HOP;
-                // tap e of this frame sits at s0 + e + frame_skew(fr + e / 160); e / 160 is fixed per step except at step 10
-                const float* pa0 = smp + s0 + frame_skew(fr) + 2 * lg;                 // taps e < 160
-                const float* pa1 = smp + s0 + frame_skew(fr + 1) + 2 * lg;             // taps e >= 160
-                const float* pb2 = smp + s0 + frame_skew(fr + 2) + MEL_NFFT - 2 * lg;  // mirrored taps 400 - e >= 320
-                const float* pb1 = smp + s0 + frame_skew(fr + 1) + MEL_NFFT - 2 * lg;  // mirrored taps 400 - e < 320
-                const float* pb_edge = lg == 0 ? pb2 : pb1;                            // step 10: e = 80 mirrors to 320, e > 80 below it
-                f32x4 acc[4];
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) acc[pr] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // operands of step s + 1 are read from LDS before the MFMAs of step s are issued
-                float nx[6];
-                auto fetch = [&](int s) {
-                    const float* pa = s < 20 ? pa0 : pa1;
-                    const float* pb = s < 10 ? pb2 : (s == 10 ? pb_edge : pb1);
-                    const float* pd = s < 10 ? pb2 : pb1;
-                    nx[0] = pa[8 * s], nx[1] = pa[8 * s + 1];
-                    nx[2] = pb[-8 * s], nx[3] = pd[-8 * s - 1];
-                    nx[4] = hw[8 * s], nx[5] = hw[8 * s + 1];
-                };
-                fetch(0);
-#pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    const float xa = nx[0], xc = nx[1], xb = nx[2], xd = nx[3], he = nx[4], ho = nx[5];
-                    if (s + 1 < KSTEPS) fetch(s + 1);
-                    __builtin_amdgcn_sched_barrier(0);  // keeps those reads ahead of this step's arithmetic
-                    float av[4];
-                    av[0] = he * (xa + xb);  // even samples, cosine part
-                    av[1] = ho * (xc + xd);  // odd samples, cosine part
-                    av[2] = he * (xa - xb);  // even samples, sine part
-                    av[3] = ho * (xc - xd);  // odd samples, sine part
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr)
-                        acc[pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr], tw[pr][s], acc[pr], 0, 0, 0);
+            // Tap e of frame fr sits at fr * 160 + e + frame_skew(fr + e / 160); e / 160 is fixed per step except at step 10.
+            // Forward taps (e, e + 1) are read upwards from pa*, mirrored taps (399 - e, 400 - e) from pb*, whose origin
+            // is the lowest mirrored tap.  The next 16 frames lie 16 * 160 + frame_skew(16) floats further on.
+            constexpr int MIRROR0 = MEL_NFFT - 1 - 8 * (KSTEPS - 1);
+            constexpr int ROWTILE = 16 * MEL_HOP + 32;
+            const int row0 = buf * SREG + li * MEL_HOP;
+            int qa0 = row0 + frame_skew(li) + 2 * lg;                 // taps e < 160
+            int qa1 = row0 + frame_skew(li + 1) + 2 * lg;             // taps e >= 160
+            int qb2 = row0 + frame_skew(li + 2) + MIRROR0 - 2 * lg;   // mirrored taps 400 - e >= 320
+            int qb1 = row0 + frame_skew(li + 1) + MIRROR0 - 2 * lg;   // mirrored taps 400 - e < 320
+            int qbe = lg == 0 ? qb2 : qb1;                            // step 10: e = 80 mirrors to 320, e > 80 below it
+            // opaque to the compiler: keeps every read an immediate offset from these five registers
+            asm volatile("" : "+v"(qa0), "+v"(qa1), "+v"(qb2), "+v"(qb1), "+v"(qbe));
+            // operands of step g + 2 are read from LDS before the MFMAs of step g are issued (g runs over all row tiles)
+            f32x2 fw[3], mr[3];  // (x[e], x[e+1]) and (x[399-e], x[400-e])
+            auto fetch = [&](int g) {
+                const int st = g % KSTEPS;
+                if (st == 0 && g > 0) {
+                    qa0 += ROWTILE, qa1 += ROWTILE, qb2 += ROWTILE, qb1 += ROWTILE, qbe += ROWTILE;
+                    asm volatile("" : "+v"(qa0), "+v"(qa1), "+v"(qb2), "+v"(qb1), "+v"(qbe));
                 }
-                // power spectrum |X[k]|^2 (AudioPreprocessing.swift:207): bins k and 200-k from the same four sums
+                const int pa = st < 20 ? qa0 : qa1;
+                const int pb = st < 10 ? qb2 : (st == 10 ? qbe : qb1);
+                const int pd = st < 10 ? qb2 : qb1;
+                fw[g % 3] = (f32x2){sm[pa + 8 * st], sm[pa + 8 * st + 1]};
+                mr[g % 3] = (f32x2){sm[pd + 8 * (KSTEPS - 1 - st)], sm[pb + 8 * (KSTEPS - 1 - st) + 1]};
+            };
+            // power spectrum |X[k]|^2 (AudioPreprocessing.swift:207): bins k and 200-k from the same four sums
+            auto power = [&](const f32x4 (&acc)[4], int mt) {
                 if (k <= 100) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -268,6 +256,34 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const float* __restric
                         }
                     }
                 }
+            };
+            {
+                f32x4 acc[2][4];  // two sets: a row tile's power spectrum is written while the next tile's MFMAs run
+                fetch(0);
+                fetch(1);
+#pragma unroll
+                for (int mt = 0; mt < MTILES; ++mt)
+#pragma unroll
+                for (int st = 0; st < KSTEPS; ++st) {
+                    const int g = mt * KSTEPS + st;
+                    // (x[e] + x[400-e], x[e+1] + x[399-e]) and the differences: one packed instruction each,
+                    // the mirrored pair taken with its halves swapped
+                    f32x2 sum, dif;
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(sum) : "v"(fw[g % 3]), "v"(mr[g % 3]));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
+                        : "=v"(dif) : "v"(fw[g % 3]), "v"(mr[g % 3]));
+                    if (g + 2 < MTILES * KSTEPS) fetch(g + 2);
+                    __builtin_amdgcn_sched_barrier(0);  // keeps those reads ahead of this step's arithmetic
+                    // the window is part of the twiddles: even / odd samples, cosine / sine part
+                    const float av[4] = {sum[0], sum[1], dif[0], dif[1]};
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        const f32x4 c = st == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt & 1][pr];
+                        acc[mt & 1][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr], tw[pr][st], c, 0, 0, 0);
+                    }
+                    if (st == 2 && mt > 0) power(acc[(mt - 1) & 1], mt - 1);
+                }
+                power(acc[(MTILES - 1) & 1], MTILES - 1);
             }
             buf ^= 1;
         }
@@ -400,7 +416,6 @@ void mel_tables_create(MelTables& t) {
     std::vector<float> hann(HANN_N, 0.f);
     // AudioPreprocessing.swift:161-164, evaluated in fp32 like the reference
     for (int i = 0; i <= 200; ++i) hann[i] = 0.5f * (1.0f - cosf(2.0f * (float)M_PI * (float)i / (float)MEL_NFFT));
-    t.hann = upload(hann);
 
     // Folded DFT tables as MFMA B-fragments: lane (g = lane>>4, j = lane&15) of step s, product pr,
     // bin tile nt holds T_pr[n][k] with k = 16 nt + j and n = 2 (4 s + g) (+1 for the odd products).
@@ -419,7 +434,7 @@ void mel_tables_create(MelTables& t) {
                         const double ang = 2.0 * PI * (double)((k * n) % MEL_NFFT) / (double)MEL_NFFT;
                         double val = cosine ? cos(ang) : sin(ang);
                         if (cosine && n == 200) val *= 0.5;  // the fold counts the centre tap twice
-                        v = (float)val;
+                        v = (float)(val * (double)hann[n]);  // the window rides on the twiddle
                     }
                     tw[(((size_t)s * 4 + pr) * NTILES + nt) * 64 + lane] = v;
                 }
@@ -439,7 +454,7 @@ void mel_tables_create(MelTables& t) {
 }
 
 void mel_tables_destroy(MelTables& t) {
-    (void)hipFree(t.hann); (void)hipFree(t.twid); (void)hipFree(t.fb_packed);
+    (void)hipFree(t.twid); (void)hipFree(t.fb_packed);
     t = MelTables();
 }
 
@@ -462,7 +477,7 @@ void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, co
     ProfScope ps("mel_kernel", work, s);
     // one workgroup fits per CU (142 KB of LDS); each loops over its share of the tiles
     hipLaunchKernelGGL(mel_kernel, dim3(std::min(n_tiles, cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,
-                       d_tile_utt, d_tile_f0, n_tiles, t.hann, t.twid, t.fb_packed, out, t_stride, d_max);
+                       d_tile_utt, d_tile_f0, n_tiles, t.twid, t.fb_packed, out, t_stride, d_max);
     HIP_CHECK(hipGetLastError());
 }
 
