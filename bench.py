@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--preset", default="1.7b")
-    ap.add_argument("--batch", type=int, default=1024, help="30 s clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=2048, help="30 s clips per GPU per step (2048: 200 GB of KV cache, the largest "
+                    "power of two that fits 288 GB; utterances decoded together)")
     ap.add_argument("--clip-seconds", type=float, default=30.0)
     ap.add_argument("--max-tokens", type=int, default=448)
     ap.add_argument("--no-stop-rules", action="store_true")
@@ -231,7 +232,8 @@ def main():
         label = (f"Qwen3-ASR-{args.preset} {args.weights} full transcribe (reference stop rules, max_tokens {args.max_tokens}), {what}, "
                  f"audio resident in HBM, seeded random weights of the true shapes")
     else:
-        metric = "RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips"
+        metric = ("RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips" if (args.preset, args.weights) == ("1.7b", "bf16")
+                  else f"RTFx (audio s per wall s) node-wide, {args.preset} {args.weights}, 30 s clips")
         label = (f"Qwen3-ASR-{args.preset} {args.weights} full transcribe (mel+encoder+prefill+greedy decode, reference stop "
                  f"rules, max_tokens {args.max_tokens}), {what}, audio resident in HBM, seeded random weights of the true shapes")
     if rank == 0 and not prof:

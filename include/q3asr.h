@@ -123,6 +123,10 @@ int q3asr_op_greedy_rules(q3asr_model* m, const int32_t* picks, const int32_t* s
 /* q3asr_op_read_bandwidth: GB/s of a plain streaming read of `bytes` bytes of device memory (the practical HBM read
  * ceiling reported beside the vendor peak in the benchmark's roofline; a measurement hook, no counterpart in the reference). */
 int q3asr_op_read_bandwidth(q3asr_model* m, int64_t bytes, float* gb_per_s);
+/* q3asr_op_mfma_f32_rate: TFLOP/s of a register-only stream of v_mfma_f32_16x16x4_f32 (4 independent accumulators per wave,
+ * 1 or 2 waves per SIMD on every CU): the rate the fp32 matrix pipe sustains, i.e. the practical ceiling of the log-mel
+ * kernel's folded DFT.  A measurement hook, no counterpart in the reference. */
+int q3asr_op_mfma_f32_rate(q3asr_model* m, int waves_per_simd, int iters, float* tflops);
 /* q3asr_op_gemm_time: average milliseconds per launch of the GEMM kernel variant (tile: 0 128x128, 1 64x64, 2 128x64,
  * 3 256x256, -1 automatic; out_kind: 0 bf16, 1 f32, 2 f32 accumulate, 3 SwiGLU, 4 argmax partials, 5 split-K slabs) on
  * device-resident pseudo-random bf16 operands, HIP events on the model's stream.  A measurement hook with no

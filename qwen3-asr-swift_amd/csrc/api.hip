@@ -228,6 +228,15 @@ int q3asr_op_read_bandwidth(q3asr_model* m, int64_t bytes, float* gb_per_s) {
     Q3_API_END
 }
 
+int q3asr_op_mfma_f32_rate(q3asr_model* m, int waves_per_simd, int iters, float* tflops) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && tflops && iters > 0 && (waves_per_simd == 1 || waves_per_simd == 2), "op_mfma_f32_rate: bad argument");
+    HIP_CHECK(hipSetDevice(m->device));
+    m->arena.reset();
+    *tflops = mfma_f32_probe_tflops(m->arena.get<float>(4), waves_per_simd, iters, m->stream);
+    Q3_API_END
+}
+
 int q3asr_op_gemm_time(q3asr_model* m, int M, int N, int K, int tile, int ksplit, int out_kind, int iters, float* ms_per_call) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && ms_per_call && iters > 0 && out_kind >= 0 && out_kind <= 5, "op_gemm_time: bad argument");

@@ -103,6 +103,8 @@ void launch_swiglu_reduce(const float* slab, int nslab, int64_t slab_stride, int
 // Average milliseconds of one streaming read of `bytes` bytes (16-byte loads, `blocks` workgroups): the HBM read
 // rate this GPU reaches, measured beside the kernels that are bound by it.
 float read_probe_ms(const void* p, size_t bytes, int blocks, int reps, hipStream_t s);
+// TFLOP/s of a register-only stream of fp32 16x16x4 MFMAs (4 independent chains per wave) with the given residency.
+float mfma_f32_probe_tflops(float* sink, int waves_per_simd, int iters, hipStream_t s);
 
 // Pseudo-random bf16 values in (-1, 1) for the kernel timing entry points.
 void launch_fill_bf16(bf16_t* p, size_t n, uint32_t seed, hipStream_t s);

@@ -495,7 +495,45 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const uint4* __restrict
     for (; i < n; i += stride) { const uint4 v = p[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
     if (acc.x == 0x9E3779B9u && acc.y == 0x7F4A7C15u && acc.z == 0xF39CC060u && acc.w == 0x5CEDC834u) *sink = acc;
 }
+// Register-only stream of independent v_mfma_f32_16x16x4_f32: what the fp32 matrix pipe sustains on this GPU.
+template <int CHAINS>
+__global__ __launch_bounds__(512) void mfma_f32_probe_kernel(float* sink, int iters) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float a = 1.0f + (float)threadIdx.x * 1e-6f, b = 1.0f - (float)blockIdx.x * 1e-7f;
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    if (s == 12345.678f) *sink = s;
+}
 }  // namespace
+
+float mfma_f32_probe_tflops(float* sink, int waves_per_simd, int iters, hipStream_t s) {
+    int dev = 0, cus = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int threads = 256 * waves_per_simd, blocks = cus * 4;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_f32_probe_kernel<4>, dim3(blocks), dim3(threads), 0, s, sink, 16);
+    HIP_CHECK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(mfma_f32_probe_kernel<4>, dim3(blocks), dim3(threads), 0, s, sink, iters);
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_CHECK(hipGetLastError());
+    const double flops = (double)blocks * (threads / 64) * (double)iters * 4 * 2048.0;
+    return (float)(flops / (ms * 1e-3) / 1e12);
+}
 
 float read_probe_ms(const void* p, size_t bytes, int blocks, int reps, hipStream_t s) {
     hipEvent_t e0, e1;

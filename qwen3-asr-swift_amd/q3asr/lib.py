@@ -41,7 +41,7 @@ EXPORTS = [
     "q3asr_last_error", "q3asr_create", "q3asr_destroy", "q3asr_load_tensor", "q3asr_finalize", "q3asr_mel_filterbank",
     "q3asr_mel", "q3asr_encode", "q3asr_output_length", "q3asr_transcribe_tokens", "q3asr_op_gemm", "q3asr_op_gemm_q4",
     "q3asr_op_attention", "q3asr_profile_start", "q3asr_profile_stop", "q3asr_op_gemm_time", "q3asr_op_greedy_rules",
-    "q3asr_op_read_bandwidth",
+    "q3asr_op_read_bandwidth", "q3asr_op_mfma_f32_rate",
 ]
 
 
@@ -70,6 +70,7 @@ def load():
     lib.q3asr_op_gemm_time.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P(ctypes.c_float)]
     lib.q3asr_op_greedy_rules.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.q3asr_op_read_bandwidth.argtypes = [c_void_p, ctypes.c_int64, P(ctypes.c_float)]
+    lib.q3asr_op_mfma_f32_rate.argtypes = [c_void_p, c_int, c_int, P(ctypes.c_float)]
     lib.q3asr_profile_start.argtypes = [c_void_p, c_int]
     lib.q3asr_profile_stop.argtypes = [c_void_p, ctypes.c_char_p, c_int]
     return lib

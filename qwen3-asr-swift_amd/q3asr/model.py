@@ -308,6 +308,12 @@ class Qwen3ASRModel:
         _lib.check(self._lib, self._lib.q3asr_op_read_bandwidth(self._h, int(nbytes), ctypes.byref(v)))
         return v.value
 
+    def op_mfma_f32_rate(self, waves_per_simd=2, iters=20000):
+        """TFLOP/s of back-to-back fp32 16x16x4 MFMAs from registers (the log-mel transform's practical ceiling)."""
+        out = ctypes.c_float()
+        _lib.check(self._lib, self._lib.q3asr_op_mfma_f32_rate(self._h, int(waves_per_simd), int(iters), ctypes.byref(out)))
+        return float(out.value)
+
     def op_gemm_time(self, M, N, K, tile=-1, ksplit=1, out_kind=0, iters=20):
         """Average ms per launch of one GEMM kernel variant on device-resident random operands."""
         ms = ctypes.c_float()
