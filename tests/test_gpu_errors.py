@@ -2,6 +2,7 @@
 weights, WeightLoading.swift:190-203; this library must not), a model that stays usable after a rejected call, and
 loading from a checkpoint directory as `fromPretrained` does (Qwen3ASR.swift:693-770)."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -81,3 +82,38 @@ def test_from_pretrained_directory(tmp_path):
     finally:
         a.close()
         b.close()
+
+
+def test_cli_transcribes_wav_files_from_a_model_directory(tmp_path):
+    """scripts/transcribe.py (the reference CLI's `transcribe`, main.swift:297-315): model directory + WAV files in,
+    one line per file out; equals the in-process result on the reference's own 24 kHz test clip."""
+    import subprocess
+    import sys
+    from conftest import GOLDEN, read_wav_pcm16
+    cfg = make_config("tiny")
+    ck = synth.make_checkpoint(cfg, seed=4)
+    save_file(tmp_path / "model.safetensors", ck)
+    config = {"thinker_config": {
+        "text_config": dict(hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                            num_key_value_heads=cfg.kv_heads, head_dim=cfg.head_dim, intermediate_size=cfg.inter,
+                            vocab_size=cfg.vocab, rms_norm_eps=1e-6, rope_theta=1e6),
+        "audio_config": dict(d_model=cfg.enc_d_model, encoder_layers=cfg.enc_layers, encoder_attention_heads=cfg.enc_heads,
+                             encoder_ffn_dim=cfg.enc_ffn, output_dim=cfg.enc_out_dim, downsample_hidden_size=cfg.conv_channels,
+                             num_mel_bins=128, n_window=50, n_window_infer=800)}}
+    (tmp_path / "config.json").write_text(json.dumps(config))
+    wav = os.path.join(GOLDEN, "test_audio.wav")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "scripts", "transcribe.py"), str(tmp_path), wav, wav, "--max-tokens", "6"],
+                         capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith(wav + ": ")]
+    assert len(lines) == 2 and lines[0] == lines[1]
+    audio, rate = read_wav_pcm16(wav)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        want = m.transcribe_batch([audio], rate, max_tokens=6).tokens[0]
+    finally:
+        m.close()
+    while want and want[-1] in (151645, 151643):      # the joined form drops a closing EOS
+        want.pop()
+    assert lines[0] == wav + ": " + " ".join(str(t) for t in want)

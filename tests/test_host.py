@@ -197,6 +197,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_shard_by_given_costs():
+    """A recording that will be cut into pieces is placed by the summed cost of its pieces, not by its own length."""
+    from q3asr.shard import shard_utterances
+    lens = [16000 * 300, 16000 * 30, 16000 * 30, 16000 * 30]
+    by_length = shard_utterances(lens, 2)                     # every clip capped at 30 s of work: 2 + 2
+    assert sorted(len(s) for s in by_length) == [2, 2]
+    by_cost = shard_utterances(lens, 2, costs=[10.0, 1.0, 1.0, 1.0])
+    assert sorted(by_cost, key=len) == [[0], [1, 2, 3]]
+    assert sorted(i for s in by_cost for i in s) == [0, 1, 2, 3]
+
+
 def test_sharded_transcribe_gathers_over_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
