@@ -5,6 +5,7 @@
 // the GEMMs, and decoded together with per-utterance KV-cache lengths; the stop rules run on the
 // device and the host only polls a counter every few steps.
 #include "model.h"
+#include "gemv.h"
 #include "prof.h"
 #include <algorithm>
 #include <cmath>
@@ -631,6 +632,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             float* hid; bf16_t *xn, *qkvb, *qd, *att, *act, *x_last; float* slab;
             int* active_dev;
             q3asr_model::DecodePlan plan;
+            bool gemv;  // a handful of rows: projections as fused GEMV kernels (gemv.hip), no partial-sum slabs
         } hv[2];
         for (int h = 0; h < n_half; ++h) {
             Half& x = hv[h];
@@ -648,7 +650,11 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             // Few rows, wide weights: every projection may be split along K so that enough workgroups
             // stream the weights; the partial sums are reduced by whichever kernel consumes them next.
             // The (tile, split) pair of each projection is measured once per row count.
-            x.plan = decode_plan(c, x.n, wf);
+            const char* env_gemv = getenv("Q3ASR_DECODE_GEMV");
+            x.gemv = !(env_gemv && atoi(env_gemv) == 0) && gemv_supports(x.n, QKV, H, GEMV_NORM_BF16, wf) &&
+                     gemv_supports(x.n, H, nh * hd, GEMV_ACC_F32, wf) && gemv_supports(x.n, 2 * cfg.inter, H, GEMV_NORM_SWIGLU, wf) &&
+                     gemv_supports(x.n, H, cfg.inter, GEMV_ACC_F32, wf);
+            x.plan = x.gemv ? q3asr_model::DecodePlan{} : decode_plan(c, x.n, wf);
             size_t slab_elems = (size_t)x.plan.ks[0] * x.n * QKV;
             slab_elems = std::max(slab_elems, (size_t)x.plan.ks[1] * x.n * H);
             slab_elems = std::max(slab_elems, (size_t)x.plan.ks[2] * x.n * 2 * cfg.inter);
@@ -702,9 +708,17 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 bf16_t* vl = vc + l * layer_stride;
                 for (int h = 0; h < n_half; ++h) {
                     const Half& x = hv[h];
-                    // residual += previous layer's down-projection partials (if it left any), then input norm
-                    launch_rmsnorm(x.hid, L.in_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.n * H, x.s);
-                    qkv_slabs[h] = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
+                    if (x.gemv) {  // input norm inside the q/k/v kernel
+                        GemvParams g;
+                        g.w = L.qkv.w; g.N = QKV; g.K = H; g.M = x.n; g.hid = x.hid; g.norm_w = L.in_norm; g.eps = cfg.rms_eps;
+                        g.out = x.qkvb; g.ldo = QKV;
+                        launch_gemv(g, GEMV_NORM_BF16, x.s);
+                        qkv_slabs[h] = 0;
+                    } else {
+                        // residual += previous layer's down-projection partials (if it left any), then input norm
+                        launch_rmsnorm(x.hid, L.in_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.n * H, x.s);
+                        qkv_slabs[h] = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
+                    }
                     if (!fuse_rope) {
                         const int ns = qkv_slabs[h];
                         RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.n * QKV, x.qd, (int64_t)nh * hd, x.n,
@@ -737,6 +751,18 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 }
                 for (int h = 0; h < n_half; ++h) {
                     const Half& x = hv[h];
+                    if (x.gemv) {  // o (+= residual), post norm + gate/up + SwiGLU, down (+= residual)
+                        GemvParams g;
+                        g.M = x.n; g.eps = cfg.rms_eps;
+                        g.w = L.o.w; g.N = H; g.K = nh * hd; g.a = x.att; g.lda = (int64_t)nh * hd; g.out = x.hid; g.ldo = H;
+                        launch_gemv(g, GEMV_ACC_F32, x.s);
+                        g.w = L.gate_up.w; g.N = 2 * cfg.inter; g.K = H; g.hid = x.hid; g.norm_w = L.post_norm; g.out = x.act; g.ldo = cfg.inter;
+                        launch_gemv(g, GEMV_NORM_SWIGLU, x.s);
+                        g.w = L.down.w; g.N = H; g.K = cfg.inter; g.a = x.act; g.lda = cfg.inter; g.out = x.hid; g.ldo = H;
+                        launch_gemv(g, GEMV_ACC_F32, x.s);
+                        pend_down[h] = 0;
+                        continue;
+                    }
                     const int ns_o = proj(x, x.att, (int64_t)nh * hd, L.o, 1, OUT_F32_ACC, x.hid, H);
                     launch_rmsnorm(x.hid, L.post_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, ns_o, (int64_t)x.n * H, x.s);
                     const int ns_gu = proj(x, x.xn, H, L.gate_up, 2, OUT_SWIGLU, x.act, cfg.inter);
@@ -751,6 +777,8 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 step(1, x.r0, x.n, x.active_dev, x.s);
             }
         };
+        // (Dealing one head's keys to several workgroups with a last-arriver merge was measured at one utterance: no gain,
+        // the kernel's fixed prologue and the merge's fences cost what the shorter key loop saves.)
         // (Replaying the step as a HIP graph was measured at 1, 8, 32 and 64 utterances: no change -- even one
         // utterance is bound by streaming the 3.4 GB of weights per step, not by the host's launch rate.)
         for (int it = 1; it < max_tokens && active > 0; ++it) {

@@ -56,7 +56,7 @@ def tiny_model():
 
 @pytest.fixture()
 def pinned_model(monkeypatch):
-    """A fresh tiny model whose decode projections are pinned to one kernel variant (64x64 tile, no split).  The library
+    """A fresh tiny model whose decode projections are pinned to one kernel variant (64x64 MFMA tile, no split, at every group size).  The library
     otherwise measures the variants per group size, and two group sizes may then sum in different orders: fine within
     the logit tolerance, but a free-running greedy decode can take another branch at a near-tie.  Tests that demand
     token-for-token equality between differently shaped runs use this model."""
@@ -64,6 +64,7 @@ def pinned_model(monkeypatch):
     monkeypatch.setenv("Q3ASR_DECODE_TILE", "1")
     monkeypatch.setenv("Q3ASR_DECODE_SPLIT", "1")
     monkeypatch.setenv("Q3ASR_DECODE_NO_FUSE", "1")
+    monkeypatch.setenv("Q3ASR_DECODE_GEMV", "0")       # groups of up to four rows would otherwise take the GEMV kernels
     cfg = make_config("tiny")
     ck = synth.make_checkpoint(cfg, seed=1)
     m = Qwen3ASRModel.from_checkpoint(cfg, ck, device=0)

@@ -127,7 +127,7 @@ def test_ragged_corpus_in_groups(monkeypatch):
     """40 utterances of 0.2-33 s through a model that decodes at most 12 at a time: several length-sorted groups,
     results back in request order, audio-token counts by the reference's length algebra (AudioEncoder.swift:254-270),
     and every fifth utterance identical to its own single-utterance run."""
-    for k, v in (("Q3ASR_DECODE_TILE", "1"), ("Q3ASR_DECODE_SPLIT", "1"), ("Q3ASR_DECODE_NO_FUSE", "1")):
+    for k, v in (("Q3ASR_DECODE_TILE", "1"), ("Q3ASR_DECODE_SPLIT", "1"), ("Q3ASR_DECODE_NO_FUSE", "1"), ("Q3ASR_DECODE_GEMV", "0")):
         monkeypatch.setenv(k, v)        # one kernel variant for every group size (see conftest.pinned_model)
     cfg = make_config("tiny", max_batch=12)
     ck = synth.make_checkpoint(cfg, seed=1)
@@ -182,6 +182,30 @@ def test_rope_inside_attention_equals_separate_kernel(variant, monkeypatch):
         # the new key's score is an fp32 VALU dot product in one path and an MFMA in the other; a flipped bf16
         # rounding of an attention output moves a logit by ~1e-3 of the largest
         assert _rel(fused.taps["logits"], plain.taps["logits"]) <= 5e-3
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("n_utt", [1, 3, 4])
+def test_few_row_projection_kernels_equal_the_mfma_path(n_utt, monkeypatch):
+    """Groups of up to four utterances decode through the fused GEMV kernels (norm + q/k/v, o += residual,
+    norm + gate/up + SwiGLU, down += residual); the MFMA path (Q3ASR_DECODE_GEMV=0) must give the same logits up to
+    bf16 rounding noise on a teacher-forced run (parity with the restatement itself: test_transcribe_teacher_forced_logits,
+    whose single utterance takes these kernels)."""
+    cfg = make_config("tiny")
+    ck = synth.make_checkpoint(cfg, seed=21)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        audios = [synth.synth_audio(n, 60 + i) for i, n in enumerate((30000, 52000, 16000, 81000)[:n_utt])]
+        forced = np.tile(np.arange(300, 310, dtype=np.int32), (n_utt, 1))
+        gemv = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
+        monkeypatch.setenv("Q3ASR_DECODE_GEMV", "0")
+        mfma = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
+        assert np.isfinite(gemv.taps["logits"]).all()
+        # Two bf16 pipelines that round their activations at different sums: measured 5e-3 of the largest logit at every
+        # step (no growth), the same as either path's distance to the fp32 restatement on this model.
+        assert _rel(gemv.taps["logits"], mfma.taps["logits"]) <= 1e-2
+        assert np.array_equal(gemv.taps["logits"][:, 0], mfma.taps["logits"][:, 0])   # step 0 is the prefill, shared by both
     finally:
         m.close()
 
