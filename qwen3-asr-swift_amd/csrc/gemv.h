@@ -13,7 +13,10 @@ enum GemvMode {
 };
 
 struct GemvParams {
-    const void* w = nullptr;  // [N][K] bf16, K contiguous
+    const void* w = nullptr;  // [N][K] bf16, K contiguous; or u32 [N][K/8] 4-bit codes when scales is set
+    const bf16_t* scales = nullptr;  // MLX affine 4-bit: [N][K/64] bf16 scale and bias
+    const bf16_t* biases = nullptr;
+    int qgroup = 64;
     int N = 0, K = 0, M = 0;
     const float* hid = nullptr;     // NORM modes: fp32 residual rows [M][K]
     const float* norm_w = nullptr;  //             RMSNorm weight [K]

@@ -18,7 +18,10 @@ constexpr int GEMV_THREADS = 256;
 // share of the row -- NCH chunks of 8 weights, 512 apart -- is requested in one burst before anything else happens, so the
 // whole projection is in flight at once (a layer's matrices are smaller than what HBM needs outstanding to reach its rate);
 // the activation rows are normalised / copied into LDS underneath those loads.
-template <int MODE, int M, int NCH>
+// WQ: MLX affine 4-bit weights (u32 codes, low nibble first, bf16 scale and bias per 64 weights of a row;
+// QuantizedTextDecoder.swift:54-67).  A chunk is then 16 weights per lane, 1024 apart, and every weight is rebuilt as
+// bf16(q * scale + bias), the value the MFMA path multiplies with.
+template <int MODE, int M, int NCH, bool WQ>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t xs[];  // [M][K]
     __shared__ float part[M][4];
@@ -27,7 +30,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvParams p) {
     const int K = p.K;
 
     // ---- activation loads first (their consumers run while the weights are still in flight) ----
-    constexpr int NA = (M * NCH * 64 + GEMV_THREADS - 1) / GEMV_THREADS;  // 16-byte pieces of the bf16 rows per thread
+    constexpr int NA = (M * NCH * 64 * (WQ ? 2 : 1) + GEMV_THREADS - 1) / GEMV_THREADS;  // 16-byte pieces of the bf16 rows per thread
     uint4 av[MODE == GEMV_ACC_F32 ? NA : 1];
     float4 v[MODE == GEMV_ACC_F32 ? 1 : M][2];
     const int d4 = K >> 2, k8 = K >> 3;
@@ -57,13 +60,23 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvParams p) {
         row[0] = blockIdx.x * 4 + wave;
     }
     const bf16_t* w = (const bf16_t*)p.w;
-    uint4 wv[R][NCH];
+    constexpr int PER_LANE = WQ ? 16 : 8;   // weights per lane and chunk
+    uint4 wv[R][NCH];                       // WQ: .x/.y = codes, .z = scale and bias bits
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int k0 = (c * 64 + lane) * 8;
-            wv[r][c] = (row[r] < p.N && k0 < K) ? *(const uint4*)(w + (int64_t)row[r] * K + k0) : make_uint4(0, 0, 0, 0);
+            const int k0 = (c * 64 + lane) * PER_LANE;
+            wv[r][c] = make_uint4(0, 0, 0, 0);
+            if (row[r] < p.N && k0 < K) {
+                if (WQ) {
+                    const uint2 codes = *(const uint2*)((const uint32_t*)p.w + (int64_t)row[r] * (K >> 3) + (k0 >> 3));
+                    const int64_t g = (int64_t)row[r] * (K >> 6) + (k0 >> 6);
+                    wv[r][c] = make_uint4(codes.x, codes.y, (uint32_t)p.scales[g] | ((uint32_t)p.biases[g] << 16), 0);
+                } else {
+                    wv[r][c] = *(const uint4*)(w + (int64_t)row[r] * K + k0);
+                }
+            }
         }
 
     // ---- activation rows into LDS ----
@@ -110,8 +123,34 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvParams p) {
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int k0 = (c * 64 + lane) * 8;
-        if (k0 < K) {
+        const int k0 = (c * 64 + lane) * PER_LANE;
+        if (WQ) {
+            if (k0 < K) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {   // 8 weights per code word
+                    float wf[R][8];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t code = h ? wv[r][c].y : wv[r][c].x;
+                        const float sc = __uint_as_float(wv[r][c].z << 16), bi = __uint_as_float(wv[r][c].z & 0xffff0000u);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) wf[r][j] = bf16_to_f32(f32_to_bf16((float)((code >> (4 * j)) & 15u) * sc + bi));
+                    }
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const uint4 xv = *(const uint4*)(xs + m * K + k0 + 8 * h);
+                        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[r][m] = fmaf(wf[r][2 * e], __uint_as_float(xw[e] << 16), acc[r][m]);
+                                acc[r][m] = fmaf(wf[r][2 * e + 1], __uint_as_float(xw[e] & 0xffff0000u), acc[r][m]);
+                            }
+                    }
+                }
+            }
+        } else if (k0 < K) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const uint4 xv = *(const uint4*)(xs + m * K + k0);
@@ -150,21 +189,29 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvParams p) {
     }
 }
 
-template <int MODE, int M, int NCH>
+template <int MODE, int M, int NCH, bool WQ>
 void launch_one(const GemvParams& p, hipStream_t s) {
     const int rows = MODE == GEMV_NORM_SWIGLU ? p.N / 2 : p.N;   // waves needed
     const size_t lds = (size_t)p.M * p.K * sizeof(bf16_t);
-    hipLaunchKernelGGL((gemv_kernel<MODE, M, NCH>), dim3(cdiv(rows, 4)), dim3(GEMV_THREADS), lds, s, p);
+    hipLaunchKernelGGL((gemv_kernel<MODE, M, NCH, WQ>), dim3(cdiv(rows, 4)), dim3(GEMV_THREADS), lds, s, p);
 }
 
 template <int MODE, int M>
 void launch_rows(const GemvParams& p, hipStream_t s) {
+    if (p.scales) {   // 4-bit weights: 1024 per wave and chunk
+        const int nch = cdiv(p.K, 1024);
+        if (nch <= 1) launch_one<MODE, M, 1, true>(p, s);
+        else if (nch <= 2) launch_one<MODE, M, 2, true>(p, s);
+        else if (nch <= 3) launch_one<MODE, M, 3, true>(p, s);
+        else launch_one<MODE, M, 6, true>(p, s);
+        return;
+    }
     const int nch = cdiv(p.K, 512);
-    if (nch <= 1) launch_one<MODE, M, 1>(p, s);
-    else if (nch <= 2) launch_one<MODE, M, 2>(p, s);
-    else if (nch <= 4) launch_one<MODE, M, 4>(p, s);
-    else if (nch <= 6) launch_one<MODE, M, 6>(p, s);
-    else launch_one<MODE, M, 12>(p, s);
+    if (nch <= 1) launch_one<MODE, M, 1, false>(p, s);
+    else if (nch <= 2) launch_one<MODE, M, 2, false>(p, s);
+    else if (nch <= 4) launch_one<MODE, M, 4, false>(p, s);
+    else if (nch <= 6) launch_one<MODE, M, 6, false>(p, s);
+    else launch_one<MODE, M, 12, false>(p, s);
 }
 
 template <int MODE>
@@ -180,17 +227,19 @@ void launch_mode(const GemvParams& p, hipStream_t s) {
 }  // namespace
 
 bool gemv_supports(int rows, int N, int K, int mode, int wfmt) {
-    if (wfmt != W_BF16 || rows < 1 || rows > GEMV_MAX_ROWS || K % 8 != 0 || K > GEMV_MAX_K) return false;
+    if (rows < 1 || rows > GEMV_MAX_ROWS || K % 8 != 0 || K > GEMV_MAX_K) return false;
+    if (wfmt == W_Q4 && K % 64 != 0) return false;   // one scale / bias per 64 weights
     if (mode != GEMV_ACC_F32 && K > 2048) return false;   // the fused RMSNorm holds a row as two float4 per thread
     if (mode == GEMV_NORM_SWIGLU && N % 16 != 0) return false;
     return true;
 }
 
 void launch_gemv(const GemvParams& p, int mode, hipStream_t s) {
-    Q3_REQUIRE(gemv_supports(p.M, p.N, p.K, mode, W_BF16), "gemv: unsupported shape");
+    Q3_REQUIRE(gemv_supports(p.M, p.N, p.K, mode, p.scales ? W_Q4 : W_BF16), "gemv: unsupported shape");
+    Q3_REQUIRE(!p.scales || (p.biases && p.qgroup == 64), "gemv: 4-bit weights need scales, biases and groups of 64");
     Q3_REQUIRE(((uintptr_t)p.w & 15) == 0, "gemv: weights must be 16-byte aligned");
     static const char* names[3] = {"gemv_kernel<norm,bf16>", "gemv_kernel<acc_f32>", "gemv_kernel<norm,swiglu>"};
-    ProfScope ps(names[mode], (double)p.N * p.K * 2.0, s);   // work = weight bytes streamed
+    ProfScope ps(names[mode], (double)p.N * p.K * (p.scales ? 0.5625 : 2.0), s);   // work = weight bytes streamed
     switch (mode) {
         case GEMV_NORM_BF16: launch_mode<GEMV_NORM_BF16>(p, s); break;
         case GEMV_ACC_F32: launch_mode<GEMV_ACC_F32>(p, s); break;

@@ -294,7 +294,8 @@ __device__ __forceinline__ void amax_block(float bv, int bi, int* out) {
         }
         __syncthreads();
     }
-    if (tid == 0) *out = si[0];
+    // a row without a single comparable value (all NaN) yields index 0, never an id outside the vocabulary
+    if (tid == 0) *out = si[0] == 0x7fffffff ? 0 : si[0];
 }
 __global__ __launch_bounds__(256) void argmax_reduce_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nparts,
                                                             int* __restrict__ out) {

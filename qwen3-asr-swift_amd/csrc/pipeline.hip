@@ -497,6 +497,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
     if (req->forced_tokens) {
         std::vector<int> f((size_t)b * max_tokens);
         for (int i = 0; i < b; ++i) memcpy(&f[(size_t)i * max_tokens], req->forced_tokens + (size_t)idx[i] * max_tokens, (size_t)max_tokens * 4);
+        for (int t : f) Q3_REQUIRE(t >= 0 && t < cfg.vocab, "transcribe: forced token id out of range");
         d_forced = c.up(f);
     }
     auto head_tile_for = [&](int rows) {  // 256x256 once the rows fill more than half of the tile
@@ -710,7 +711,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                     const Half& x = hv[h];
                     if (x.gemv) {  // input norm inside the q/k/v kernel
                         GemvParams g;
-                        g.w = L.qkv.w; g.N = QKV; g.K = H; g.M = x.n; g.hid = x.hid; g.norm_w = L.in_norm; g.eps = cfg.rms_eps;
+                        g.w = L.qkv.w; g.scales = L.qkv.scales; g.biases = L.qkv.biases; g.qgroup = cfg.group_size; g.N = QKV; g.K = H; g.M = x.n; g.hid = x.hid; g.norm_w = L.in_norm; g.eps = cfg.rms_eps;
                         g.out = x.qkvb; g.ldo = QKV;
                         launch_gemv(g, GEMV_NORM_BF16, x.s);
                         qkv_slabs[h] = 0;
@@ -753,12 +754,12 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                     const Half& x = hv[h];
                     if (x.gemv) {  // o (+= residual), post norm + gate/up + SwiGLU, down (+= residual)
                         GemvParams g;
-                        g.M = x.n; g.eps = cfg.rms_eps;
-                        g.w = L.o.w; g.N = H; g.K = nh * hd; g.a = x.att; g.lda = (int64_t)nh * hd; g.out = x.hid; g.ldo = H;
+                        g.M = x.n; g.eps = cfg.rms_eps; g.qgroup = cfg.group_size;
+                        g.w = L.o.w; g.scales = L.o.scales; g.biases = L.o.biases; g.N = H; g.K = nh * hd; g.a = x.att; g.lda = (int64_t)nh * hd; g.out = x.hid; g.ldo = H;
                         launch_gemv(g, GEMV_ACC_F32, x.s);
-                        g.w = L.gate_up.w; g.N = 2 * cfg.inter; g.K = H; g.hid = x.hid; g.norm_w = L.post_norm; g.out = x.act; g.ldo = cfg.inter;
+                        g.w = L.gate_up.w; g.scales = L.gate_up.scales; g.biases = L.gate_up.biases; g.N = 2 * cfg.inter; g.K = H; g.hid = x.hid; g.norm_w = L.post_norm; g.out = x.act; g.ldo = cfg.inter;
                         launch_gemv(g, GEMV_NORM_SWIGLU, x.s);
-                        g.w = L.down.w; g.N = H; g.K = cfg.inter; g.a = x.act; g.lda = cfg.inter; g.out = x.hid; g.ldo = H;
+                        g.w = L.down.w; g.scales = L.down.scales; g.biases = L.down.biases; g.N = H; g.K = cfg.inter; g.a = x.act; g.lda = cfg.inter; g.out = x.hid; g.ldo = H;
                         launch_gemv(g, GEMV_ACC_F32, x.s);
                         pend_down[h] = 0;
                         continue;

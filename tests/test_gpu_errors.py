@@ -55,6 +55,8 @@ def test_rejected_calls_leave_the_model_usable(tiny_model):
         m.transcribe_batch([audio], 16000, max_tokens=4, lang_ids=[[cfg.vocab + 5]])
     with pytest.raises(Q3Error, match="multiple of 32"):
         m.op_gemm(np.zeros((4, 40), np.uint16), np.zeros((8, 40), np.uint16))
+    with pytest.raises(Q3Error, match="forced token id out of range"):
+        m.transcribe_batch([audio], 16000, max_tokens=4, forced_tokens=np.full((1, 4), 1 << 30, np.int32))
     assert m.transcribe_batch([audio], 16000, max_tokens=4, stop_rules=False).tokens == good
 
 

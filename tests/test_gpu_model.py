@@ -186,13 +186,14 @@ def test_rope_inside_attention_equals_separate_kernel(variant, monkeypatch):
         m.close()
 
 
+@pytest.mark.parametrize("q4", [False, True])
 @pytest.mark.parametrize("n_utt", [1, 3, 4])
-def test_few_row_projection_kernels_equal_the_mfma_path(n_utt, monkeypatch):
+def test_few_row_projection_kernels_equal_the_mfma_path(n_utt, q4, monkeypatch):
     """Groups of up to four utterances decode through the fused GEMV kernels (norm + q/k/v, o += residual,
     norm + gate/up + SwiGLU, down += residual); the MFMA path (Q3ASR_DECODE_GEMV=0) must give the same logits up to
     bf16 rounding noise on a teacher-forced run (parity with the restatement itself: test_transcribe_teacher_forced_logits,
     whose single utterance takes these kernels)."""
-    cfg = make_config("tiny")
+    cfg = make_config("tiny", weight_format=1 if q4 else 0)      # q4: MLX affine 4-bit decoder weights
     ck = synth.make_checkpoint(cfg, seed=21)
     m = Qwen3ASRModel.from_checkpoint(cfg, ck)
     try:
@@ -210,12 +211,12 @@ def test_few_row_projection_kernels_equal_the_mfma_path(n_utt, monkeypatch):
         m.close()
 
 
-@pytest.mark.parametrize("preset", ["0.6b", "1.7b"])
+@pytest.mark.parametrize("preset", ["0.6b", "1.7b", "0.6b-q4"])
 def test_true_widths_two_layers(preset):
     """The real layer widths (896 / 1024 encoder, 1024 / 2048 decoder, 14 / 16 encoder heads, 16 Q / 8 KV heads,
     vocabulary 151 936) with two layers per stack, so that the CPU restatement finishes in seconds: catches tile-edge
     and head-count assumptions the tiny configuration cannot."""
-    cfg = make_config(preset, enc_layers=2, layers=2)
+    cfg = make_config(preset.split("-")[0], enc_layers=2, layers=2, weight_format=1 if preset.endswith("q4") else 0)
     ck = synth.make_checkpoint(cfg, seed=5)
     audio = synth.synth_audio(16000 * 2 + 800, 31)
     steps = 4
