@@ -20,7 +20,6 @@ constexpr int TOK_AUDIO_PAD = 151676, TOK_ASR_TEXT = 151704, TOK_NEWLINE = 198, 
 constexpr int TOK_ASSISTANT = 77091;
 constexpr int ENC_CHUNK_BUDGET = 3840;  // chunks per encoder pass (128 clips of 30 s; conv1's output is 3 MB per chunk;
                                         // measured: 960 -> 673 ms, 3840 -> 590 ms, 7680 -> 581 ms per 1024 clips)
-constexpr int PREFILL_ROW_BUDGET = 32768;
 constexpr int POLL_STEPS = 8;
 
 inline int conv_len(int n) { return (n - 1) / 2 + 1; }
