@@ -133,23 +133,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 const int v = (tail && kbase + w_koff[q] >= p.K) ? BUF_OOB : w_voff[q];
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(sw + (q * 256 + uwave * 64) * 16), 16, v, kbase * 2, 0, 0);
             }
-        } else {
-            // MLX affine 4-bit: one u32 = 8 codes = one 16-byte bf16 chunk; dequantised in registers
-            // (w = q * scale + bias, rounded to bf16) and written to the swizzled LDS slot.
+        }
+    };
+    // MLX affine 4-bit weights: one u32 = 8 codes = one 16-byte bf16 chunk.  The codes, scale and bias of a K tile are
+    // fetched into registers a whole iteration before they are dequantised (w = q * scale + bias, rounded to bf16) and
+    // written to the swizzled LDS slot, so their latency hides behind the MFMAs of the tile in between.
+    uint32_t q4_code[WFMT == W_Q4 ? WP : 1], q4_sb[WFMT == W_Q4 ? WP : 1];
+    auto q4_fetch = [&](int kt) {
+        if constexpr (WFMT == W_Q4) {
             const uint32_t* wq = (const uint32_t*)p.W;
             const int groups = p.K / p.qgroup;
 #pragma unroll
             for (int q = 0; q < WP; ++q) {
                 const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
                 const int f = ((row >> 1) & 1) | (((row / (4 * NT)) & 3) << 1);
-                const int sc = cc ^ f;
-                const int k0 = kbase + sc * 8;
+                const int k0 = kt * 64 + (cc ^ f) * 8;
                 const int n = min(n0 + row, p.N - 1);
+                q4_code[q] = 0;
+                q4_sb[q] = 0;
+                if (k0 < p.K) {
+                    q4_code[q] = wq[(int64_t)n * (p.K >> 3) + (k0 >> 3)];
+                    q4_sb[q] = (uint32_t)p.qscales[(int64_t)n * groups + k0 / p.qgroup] |
+                               ((uint32_t)p.qbiases[(int64_t)n * groups + k0 / p.qgroup] << 16);
+                }
+            }
+        }
+    };
+    auto q4_store = [&](int buf, int kt) {
+        if constexpr (WFMT == W_Q4) {
+            char* sw = smem + buf * STAGE + A_BYTES;
+#pragma unroll
+            for (int q = 0; q < WP; ++q) {
+                const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
+                const int f = ((row >> 1) & 1) | (((row / (4 * NT)) & 3) << 1);
+                const int k0 = kt * 64 + (cc ^ f) * 8;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (k0 < p.K) {
-                    const uint32_t code = wq[(int64_t)n * (p.K >> 3) + (k0 >> 3)];
-                    const float s = bf16_to_f32(p.qscales[(int64_t)n * groups + k0 / p.qgroup]);
-                    const float b = bf16_to_f32(p.qbiases[(int64_t)n * groups + k0 / p.qgroup]);
+                    const uint32_t code = q4_code[q];
+                    const float s = __uint_as_float(q4_sb[q] << 16), b = __uint_as_float(q4_sb[q] & 0xffff0000u);
                     float w[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) w[j] = (float)((code >> (4 * j)) & 15u) * s + b;
@@ -189,12 +210,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     if (nt > 0) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
-            if (s < nt) stage(s, kt0 + s);
+            if (s < nt) {
+                q4_fetch(kt0 + s);
+                stage(s, kt0 + s);
+                q4_store(s, kt0 + s);
+            }
         for (int t = 0; t < nt; ++t) {
             if (t + STAGES - 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (t + STAGES - 1 < nt) stage((t + STAGES - 1) % STAGES, kt0 + t + STAGES - 1);
+            const bool refill = t + STAGES - 1 < nt;
+            if (refill) {
+                q4_fetch(kt0 + t + STAGES - 1);   // ahead of the LDS-direct loads, so waiting for it leaves those in flight
+                stage((t + STAGES - 1) % STAGES, kt0 + t + STAGES - 1);
+            }
             const char* sb = smem + (t % STAGES) * STAGE;
             // All fragment reads of the K tile are issued before its first MFMA (pinned: left alone, the
             // scheduler alternates small read groups with MFMAs behind full lgkmcnt waits, and a workgroup
@@ -216,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                     for (int b = 0; b < NT; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][b], af[ks][a], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (refill) q4_store((t + STAGES - 1) % STAGES, kt0 + t + STAGES - 1);
         }
     }
 
