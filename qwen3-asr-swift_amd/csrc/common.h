@@ -28,15 +28,14 @@ void q3_set_error(const std::string& msg);
 
 #ifdef __HIPCC__
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-// Round-to-nearest-even; inputs here are finite activations / weights.
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// Round-to-nearest-even through the hardware conversion (v_cvt_pk_bf16_f32): one instruction per pair of values.
+typedef __bf16 q3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float q3_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const q3_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, q3_bf16x2));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, f) & 0xffffu); }
 // Buffer descriptor over `bytes` bytes at a workgroup-uniform address.  The address goes through
 // readfirstlane so the compiler keeps the descriptor in SGPRs (otherwise every buffer instruction is
 // wrapped in a loop that re-checks its uniformity).

@@ -361,7 +361,7 @@ q3asr_model::DecodePlan decode_plan(Ctx& c, int b, GemmWFmt wf) {
         plan.fused[g] = 0;
         double best = 1e30;
         for (int tile : {1, 2, 0, 3}) {
-            if ((tile == 3 && (wf != W_BF16 || b <= 128)) || (tile == 1 && b > 128)) continue;
+            if ((tile == 3 && (wf != W_BF16 || b <= 128)) || (tile == 1 && b > 512)) continue;
             if (env_tile && atoi(env_tile) != tile) continue;
             for (int ks : {0, 1, 2, 4, 8}) {  // 0: the fused form
                 if (ks > 1 && ks * 4 > W[g]->K / 64) continue;  // at least four K tiles per split
@@ -381,6 +381,9 @@ q3asr_model::DecodePlan decode_plan(Ctx& c, int b, GemmWFmt wf) {
                 // a split's consumer reads the slabs back (~3 TB/s); gate/up partials also need the reduce kernel
                 const double extra_us = ks == 0 ? 0.0 : ks * b * (double)W[g]->N * 4.0 / 3.0e6 + (g == 2 ? 4.0 : 0.0);
                 const double us = ms * 1000.0 / REPS + extra_us;
+                if (getenv("Q3ASR_VERBOSE") && atoi(getenv("Q3ASR_VERBOSE")) > 1)
+                    fprintf(stderr, "q3asr: rows %d proj %d tile %d split %d: %.1f us (+%.1f us for its partial sums)\n", b, g, tile, ks,
+                            ms * 1000.0 / REPS, extra_us);
                 if (us < best) { best = us; plan.tile[g] = tile; plan.ks[g] = std::max(ks, 1); plan.fused[g] = ks == 0; }
             }
         }
