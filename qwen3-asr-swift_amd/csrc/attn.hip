@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
 #undef FLASH_LOAD
 
 template <int GROUP, bool FUSED>
-__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
+__global__ __launch_bounds__(256, 3) void decode_attn_kernel(DecodeAttnParams p) {
     constexpr int D = 128;
     __shared__ float sm_m[4][GROUP], sm_l[4][GROUP];
     __shared__ float so[4][GROUP][D];
