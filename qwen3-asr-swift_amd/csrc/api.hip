@@ -220,7 +220,7 @@ int q3asr_op_read_bandwidth(q3asr_model* m, int64_t bytes, float* gb_per_s) {
     char* buf = m->arena.get<char>((size_t)bytes);
     launch_fill_bf16((bf16_t*)buf, (size_t)bytes / 2, 0x77u, m->stream);
     float best = 0.f;
-    for (int blocks : {2048, 4096, 8192}) {
+    for (int blocks : {4096, 8192, 16384}) {
         const float ms = read_probe_ms(buf, (size_t)bytes, blocks, 5, m->stream);
         best = std::max(best, (float)((double)bytes / (ms * 1e-3) / 1e9));
     }

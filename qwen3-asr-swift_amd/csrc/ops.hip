@@ -482,16 +482,20 @@ void launch_fill_bf16(bf16_t* p, size_t n, uint32_t seed, hipStream_t s) {
 namespace {
 // Streaming read of n 16-byte words, eight independent loads in flight per lane; the xor of everything read is
 // stored only when it equals an impossible value, so the loads cannot be dropped.
+// Non-temporal 16-byte loads, eight in flight per lane: the fastest plain read loop found on this GPU (loads that
+// allocate in L2 reach ~10 % less).
 __global__ __launch_bounds__(256) void read_probe_kernel(const uint4* __restrict__ p, size_t n, uint4* sink) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* q = (const u32x4*)p;
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     uint4 acc = make_uint4(0, 0, 0, 0);
     for (; i + 7 * stride < n; i += 8 * stride) {
-        uint4 v[8];
+        u32x4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[i + j * stride];
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(q + i + j * stride);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
+        for (int j = 0; j < 8; ++j) { acc.x ^= v[j][0]; acc.y ^= v[j][1]; acc.z ^= v[j][2]; acc.w ^= v[j][3]; }
     }
     for (; i < n; i += stride) { const uint4 v = p[i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
     if (acc.x == 0x9E3779B9u && acc.y == 0x7F4A7C15u && acc.z == 0xF39CC060u && acc.w == 0x5CEDC834u) *sink = acc;
