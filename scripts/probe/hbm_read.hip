@@ -1,3 +1,5 @@
+// Bare HBM read loops (plain, deeper, non-temporal, contiguous chunk per block) timed with HIP events.
+//   hipcc -O3 --offload-arch=gfx950 -o hbm_read hbm_read.hip && ./hbm_read
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
