@@ -13,6 +13,7 @@
 // K/V stream).  HBM-bound: K rows go straight from global memory into MFMA A fragments, the
 // probabilities are broadcast with v_readlane, V rows are consumed coalesced by the VALU.
 #include "attn.h"
+#include <cstdlib>
 #include "prof.h"
 #include "rope.h"
 #include <algorithm>
@@ -156,11 +157,13 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
 
 #undef FLASH_LOAD
 
-template <int GROUP, bool FUSED>
-__global__ __launch_bounds__(256, 3) void decode_attn_kernel(DecodeAttnParams p) {
+// WAVES = 4 for large groups (three workgroups share a CU); 8 when there are fewer (utterance, head) items than CUs,
+// so that one item's keys are streamed by twice as many waves.
+template <int GROUP, bool FUSED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_kernel(DecodeAttnParams p) {
     constexpr int D = 128;
-    __shared__ float sm_m[4][GROUP], sm_l[4][GROUP];
-    __shared__ float so[4][GROUP][D];
+    __shared__ float sm_m[WAVES][GROUP], sm_l[WAVES][GROUP];
+    __shared__ float so[WAVES][GROUP][D];
     __shared__ __attribute__((aligned(16))) bf16_t sq[GROUP][D];  // FUSED: this step's normalised, rotated queries
     __shared__ float snew[2][D];                                  // FUSED: the new key (rotated) and value, bf16-rounded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, 3) void decode_attn_kernel(DecodeAttnParams p)
         const DecodeRopeIn& r = p.rope;
         const int heads = p.kv_heads * GROUP, pos = len;
         const RopeTables tabs{r.cos_tab, r.sin_tab, r.half, r.interleaved, r.max_pos};
-        for (int sl = wave; sl < GROUP + 2; sl += 4) {
+        for (int sl = wave; sl < GROUP + 2; sl += WAVES) {
             const int col = sl < GROUP ? (kvh * GROUP + sl) * D : (sl == GROUP ? (heads + kvh) * D : (heads + p.kv_heads + kvh) * D);
             const int64_t src = (int64_t)u * r.ld + col + 2 * lane;
             float x0, x1;
@@ -293,11 +296,11 @@ __global__ __launch_bounds__(256, 3) void decode_attn_kernel(DecodeAttnParams p)
         }
     }
     while (t < ntiles) {
-        const int t2 = t + 4;
+        const int t2 = t + WAVES;
         if (t2 < ntiles) DA_LOAD(kfB, vvB, t2);
         DA_COMPUTE(kfA, vvA, t);
         if (t2 >= ntiles) break;
-        const int t3 = t2 + 4;
+        const int t3 = t2 + WAVES;
         if (t3 < ntiles) DA_LOAD(kfA, vvA, t3);
         DA_COMPUTE(kfB, vvB, t2);
         t = t3;
@@ -332,14 +335,14 @@ __global__ __launch_bounds__(256, 3) void decode_attn_kernel(DecodeAttnParams p)
         so[wave][q][2 * lane + 1] = o[q][1];
     }
     __syncthreads();
-    for (int idx = tid; idx < GROUP * D; idx += 256) {
+    for (int idx = tid; idx < GROUP * D; idx += 64 * WAVES) {
         const int q = idx / D, d = idx % D;
         float M = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) M = fmaxf(M, sm_m[w][q]);
+        for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm_m[w][q]);
         float L = 0.f, O = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             const float f = exp2f(sm_m[w][q] - M);
             L += sm_l[w][q] * f;
             O += so[w][q][d] * f;
@@ -373,19 +376,25 @@ void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, 
     if (p.B <= 0) return;
     Q3_REQUIRE(head_dim == 128, "decode attention: head_dim must be 128");
     const int items = p.B * p.kv_heads;
-    dim3 grid(p.max_blocks > 0 ? std::min(items, p.max_blocks) : items), block(256);
+    const char* env_waves = getenv("Q3ASR_ATTN_WAVES");   // 4 or 8: pins the variant (tests, tuning)
+    const bool wide = env_waves ? atoi(env_waves) == 8 : items < 256;   // fewer items than CUs: eight waves per item
+    dim3 grid(p.max_blocks > 0 ? std::min(items, p.max_blocks) : items), block(wide ? 512 : 256);
     ProfScope ps("decode_attn_kernel", work, s);
     const bool fused = p.rope.qkv || p.rope.slab;
     if (fused) Q3_REQUIRE(p.len_add == 0 && p.rope.ld % 2 == 0 && p.rope.q_norm_w && p.rope.k_norm_w && p.rope.cos_tab && p.rope.sin_tab,
                           "decode attention: incomplete fused q/k/v input");
+#define DA_LAUNCH(G, F)                                                                               \
+    if (wide) hipLaunchKernelGGL((decode_attn_kernel<G, F, 8>), grid, block, 0, s, p);                \
+    else hipLaunchKernelGGL((decode_attn_kernel<G, F, 4>), grid, block, 0, s, p)
     switch (p.group * 2 + (fused ? 1 : 0)) {
-        case 2: hipLaunchKernelGGL((decode_attn_kernel<1, false>), grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL((decode_attn_kernel<1, true>), grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL((decode_attn_kernel<2, false>), grid, block, 0, s, p); break;
-        case 5: hipLaunchKernelGGL((decode_attn_kernel<2, true>), grid, block, 0, s, p); break;
-        case 8: hipLaunchKernelGGL((decode_attn_kernel<4, false>), grid, block, 0, s, p); break;
-        case 9: hipLaunchKernelGGL((decode_attn_kernel<4, true>), grid, block, 0, s, p); break;
+        case 2: DA_LAUNCH(1, false); break;
+        case 3: DA_LAUNCH(1, true); break;
+        case 4: DA_LAUNCH(2, false); break;
+        case 5: DA_LAUNCH(2, true); break;
+        case 8: DA_LAUNCH(4, false); break;
+        case 9: DA_LAUNCH(4, true); break;
         default: throw Q3Error("decode attention: GQA group must be 1, 2 or 4");
     }
+#undef DA_LAUNCH
     HIP_CHECK(hipGetLastError());
 }

@@ -46,11 +46,13 @@ def _oracle_run(cfg, ck, audio, max_tokens, embed_scale=True):
     return toks, np.stack(trace), stages
 
 
-@pytest.mark.parametrize("variant", ["default", "rotate_half", "no_embed_scale", "q4"])
-def test_transcribe_teacher_forced_logits(variant):
+@pytest.mark.parametrize("variant", ["default", "rotate_half", "no_embed_scale", "q4", "attn4"])
+def test_transcribe_teacher_forced_logits(variant, monkeypatch):
     """Per-step logits under teacher forcing with the oracle's own tokens, every decode path
     (interleaved / rotate-half RoPE, embed rescale on / off, dense / MLX-q4 weights)."""
     kw = dict(rotate_half=dict(rope_interleaved=0), no_embed_scale=dict(embed_scale=0), q4=dict(weight_format=1)).get(variant, {})
+    if variant == "attn4":      # the large groups' four-wave decode attention (a single utterance would take eight)
+        monkeypatch.setenv("Q3ASR_ATTN_WAVES", "4")
     cfg = make_config("tiny", **kw)
     ck = synth.make_checkpoint(cfg, seed=3)
     audio = synth.synth_audio(16000 * 2 + 4000, 21)
@@ -207,6 +209,27 @@ def test_few_row_projection_kernels_equal_the_mfma_path(n_utt, q4, monkeypatch):
         # step (no growth), the same as either path's distance to the fp32 restatement on this model.
         assert _rel(gemv.taps["logits"], mfma.taps["logits"]) <= 1e-2
         assert np.array_equal(gemv.taps["logits"][:, 0], mfma.taps["logits"][:, 0])   # step 0 is the prefill, shared by both
+    finally:
+        m.close()
+
+
+def test_decode_attention_wave_counts_agree(monkeypatch):
+    """Groups with fewer (utterance, kv head) pairs than CUs stream each pair's keys with eight waves instead of four
+    (every test-sized group is that small, so the four-wave kernel of the large groups is pinned here explicitly):
+    same logits up to the order in which the partial softmax results are merged."""
+    cfg = make_config("tiny")
+    ck = synth.make_checkpoint(cfg, seed=29)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        audios = [synth.synth_audio(n, 40 + i) for i, n in enumerate((32000, 480000, 90000))]
+        forced = np.tile(np.arange(500, 512, dtype=np.int32), (3, 1))
+        runs = {}
+        for waves in ("4", "8"):
+            monkeypatch.setenv("Q3ASR_ATTN_WAVES", waves)
+            runs[waves] = m.transcribe_batch(audios, 16000, max_tokens=12, forced_tokens=forced, tap_steps=12).taps["logits"]
+            assert np.isfinite(runs[waves]).all()
+        assert _rel(runs["4"], runs["8"]) <= 5e-3      # a flipped bf16 rounding of an attention output
+        assert np.array_equal(runs["4"][:, 0], runs["8"][:, 0])   # the prefill does not use this kernel
     finally:
         m.close()
 
