@@ -157,6 +157,19 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
 
 #undef FLASH_LOAD
 
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: one LDS-crossbar
+// swizzle for the row pair and one v_permlane32_swap for the wave halves, no address arithmetic.
+__device__ __forceinline__ float rows_max(float x) {
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401f)));   // lanes l ^ 16
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(h[0]), __uint_as_float(h[1]));                              // lanes l ^ 32
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    x += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401f));
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(h[0]) + __uint_as_float(h[1]);
+}
+
 // WAVES = 4 for large groups (three workgroups share a CU); 8 when there are fewer (utterance, head) items than CUs,
 // so that one item's keys are streamed by twice as many waves.
 template <int GROUP, bool FUSED, int WAVES>
@@ -209,17 +222,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
             sv[r] = (kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;                                         \
             tmax = fmaxf(tmax, sv[r]);                                                                         \
         }                                                                                                      \
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));                                                          \
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                                                          \
+        tmax = rows_max(tmax);                                                                                 \
         const float m_new = fmaxf(m, tmax);                                                                    \
-        const float alpha = exp2f(m - m_new);                                                                  \
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);                                                 \
         float pr[4], ps = 0.f;                                                                                 \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
-            pr[r] = exp2f(sv[r] - m_new);                                                                      \
+            pr[r] = __builtin_amdgcn_exp2f(sv[r] - m_new);                                                     \
             ps += pr[r];                                                                                       \
         }                                                                                                      \
-        ps += __shfl_xor(ps, 16, 64);                                                                          \
-        ps += __shfl_xor(ps, 32, 64);                                                                          \
+        ps = rows_sum(ps);                                                                                     \
         l = l * alpha + ps;                                                                                    \
         m = m_new;                                                                                             \
         /* lane (q + 16 g) holds the probabilities of keys 4 g .. 4 g + 3 for query q: broadcast them */       \
