@@ -135,49 +135,52 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             }
         }
     };
-    // MLX affine 4-bit weights: one u32 = 8 codes = one 16-byte bf16 chunk.  The codes, scale and bias of a K tile are
-    // fetched into registers a whole iteration before they are dequantised (w = q * scale + bias, rounded to bf16) and
-    // written to the swizzled LDS slot, so their latency hides behind the MFMAs of the tile in between.
-    uint32_t q4_code[WFMT == W_Q4 ? WP : 1], q4_sb[WFMT == W_Q4 ? WP : 1];
+    // MLX affine 4-bit weights: a row's 64 weights of a K tile are 8 u32 codes (32 bytes) under one scale and bias.
+    // A thread takes half a row: one 16-byte code load plus the row's scale and bias, fetched into registers a whole
+    // iteration before they are dequantised (w = q * scale + bias, rounded to bf16) and written as four 16-byte
+    // chunks to their swizzled LDS slots, so the latency hides behind the MFMAs of the tile in between.
+    constexpr bool Q4 = WFMT == W_Q4;
+    const bool q4_active = Q4 && tid < BN * 2;   // BN rows x 2 halves (all 256 threads for the 128-row tiles)
+    const int q4_row = tid >> 1, q4_half = tid & 1;
+    uint4 q4_code = make_uint4(0, 0, 0, 0);
+    uint32_t q4_sb = 0;
     auto q4_fetch = [&](int kt) {
-        if constexpr (WFMT == W_Q4) {
-            const uint32_t* wq = (const uint32_t*)p.W;
-            const int groups = p.K / p.qgroup;
-#pragma unroll
-            for (int q = 0; q < WP; ++q) {
-                const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
-                const int f = ((row >> 1) & 1) | (((row / (4 * NT)) & 3) << 1);
-                const int k0 = kt * 64 + (cc ^ f) * 8;
-                const int n = min(n0 + row, p.N - 1);
-                q4_code[q] = 0;
-                q4_sb[q] = 0;
-                if (k0 < p.K) {
-                    q4_code[q] = wq[(int64_t)n * (p.K >> 3) + (k0 >> 3)];
-                    q4_sb[q] = (uint32_t)p.qscales[(int64_t)n * groups + k0 / p.qgroup] |
-                               ((uint32_t)p.qbiases[(int64_t)n * groups + k0 / p.qgroup] << 16);
+        if constexpr (Q4) {
+            if (q4_active) {
+                const int k0 = kt * 64 + q4_half * 32;
+                const int n = min(n0 + q4_row, p.N - 1);
+                q4_code = make_uint4(0, 0, 0, 0);
+                q4_sb = 0;
+                if (k0 < p.K) {   // K is a multiple of 64, so a half row is inside or outside as a whole
+                    const int groups = p.K / p.qgroup;
+                    q4_code = *(const uint4*)((const uint32_t*)p.W + (int64_t)n * (p.K >> 3) + (k0 >> 3));
+                    q4_sb = (uint32_t)p.qscales[(int64_t)n * groups + k0 / p.qgroup] |
+                            ((uint32_t)p.qbiases[(int64_t)n * groups + k0 / p.qgroup] << 16);
                 }
             }
         }
     };
     auto q4_store = [&](int buf, int kt) {
-        if constexpr (WFMT == W_Q4) {
-            char* sw = smem + buf * STAGE + A_BYTES;
+        if constexpr (Q4) {
+            if (q4_active) {
+                char* sw = smem + buf * STAGE + A_BYTES;
+                const int f = ((q4_row >> 1) & 1) | (((q4_row / (4 * NT)) & 3) << 1);
+                const float s = __uint_as_float(q4_sb << 16), b = __uint_as_float(q4_sb & 0xffff0000u);
+                const uint32_t codes[4] = {q4_code.x, q4_code.y, q4_code.z, q4_code.w};
+                const bool inside = kt * 64 + q4_half * 32 < p.K;
 #pragma unroll
-            for (int q = 0; q < WP; ++q) {
-                const int c = q * 256 + tid, row = c >> 3, cc = c & 7;
-                const int f = ((row >> 1) & 1) | (((row / (4 * NT)) & 3) << 1);
-                const int k0 = kt * 64 + (cc ^ f) * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (k0 < p.K) {
-                    const uint32_t code = q4_code[q];
-                    const float s = __uint_as_float(q4_sb[q] << 16), b = __uint_as_float(q4_sb[q] & 0xffff0000u);
-                    float w[8];
+                for (int j = 0; j < 4; ++j) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (inside) {
+                        float w[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) w[j] = (float)((code >> (4 * j)) & 15u) * s + b;
-                    v = make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
-                                   pack_bf16x2(w[6], w[7]));
+                        for (int e = 0; e < 8; ++e) w[e] = (float)((codes[j] >> (4 * e)) & 15u) * s + b;
+                        v = make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
+                                       pack_bf16x2(w[6], w[7]));
+                    }
+                    const int logical = q4_half * 4 + j;   // 8-weight chunk of the row within this K tile
+                    *(uint4*)(sw + (q4_row * 8 + (logical ^ f)) * 16) = v;
                 }
-                *(uint4*)(sw + c * 16) = v;
             }
         }
     };
