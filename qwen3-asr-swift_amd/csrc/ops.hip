@@ -174,6 +174,77 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
     }
 }
 
+// Same operation for whole bf16 rows (prefill), four heads per wave: 16 lanes per head, lane l of a head
+// holding elements 4l..4l+3 and 64+4l..64+4l+3 (two 8-byte accesses), so that both pairings of the rotation
+// stay inside a lane: (2j, 2j+1) for the interleaved form, (i, i+64) for rotate-half over the full head.
+__global__ __launch_bounds__(256) void rope_rows_kernel(RopeParams p) {
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int slots = p.heads + 2 * p.kv_heads, groups = slots >> 2;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (int64_t)p.rows * groups) return;
+    const int row = (int)(gw / groups), slot = (int)(gw % groups) * 4 + (lane >> 4);
+    const int u = p.row_utt ? p.row_utt[row] : row;
+    const int pos = p.row_pos ? p.row_pos[row] : p.cur_len[u];
+    const bf16_t* src = p.qkv + (int64_t)row * p.ld + (int64_t)slot * 128 + 4 * l;
+    const uint2 ra = *(const uint2*)src, rb = *(const uint2*)(src + 64);
+    if (slot >= p.heads + p.kv_heads) {  // V: cached as is
+        bf16_t* dst = p.vcache + (int64_t)u * p.utt_stride + (int64_t)(slot - p.heads - p.kv_heads) * p.head_stride +
+                      (int64_t)pos * 128 + 4 * l;
+        *(uint2*)dst = ra;
+        *(uint2*)(dst + 64) = rb;
+        return;
+    }
+    const bool is_q = slot < p.heads;
+    float a[4] = {__uint_as_float(ra.x << 16), __uint_as_float(ra.x & 0xffff0000u), __uint_as_float(ra.y << 16),
+                  __uint_as_float(ra.y & 0xffff0000u)};
+    float b[4] = {__uint_as_float(rb.x << 16), __uint_as_float(rb.x & 0xffff0000u), __uint_as_float(rb.y << 16),
+                  __uint_as_float(rb.y & 0xffff0000u)};
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sq += a[i] * a[i] + b[i] * b[i];
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) sq += __shfl_xor(sq, m, 64);
+    const float rstd = 1.0f / sqrtf(sq / 128.0f + p.eps);
+    const float* w = is_q ? p.q_norm_w : p.k_norm_w;
+    const float4 wa = *(const float4*)(w + 4 * l), wb = *(const float4*)(w + 64 + 4 * l);
+    a[0] *= rstd * wa.x; a[1] *= rstd * wa.y; a[2] *= rstd * wa.z; a[3] *= rstd * wa.w;
+    b[0] *= rstd * wb.x; b[1] *= rstd * wb.y; b[2] *= rstd * wb.z; b[3] *= rstd * wb.w;
+    const int pp = min(pos, p.max_pos - 1);
+    const float* ct = p.cos_tab + (int64_t)pp * p.half;
+    const float* st = p.sin_tab + (int64_t)pp * p.half;
+    if (p.interleaved) {  // pair j = elements (2j, 2j+1), rotated when j < half
+        const int ja = 2 * l, jb = 32 + 2 * l;
+        if (ja < p.half) {
+            const float2 c = *(const float2*)(ct + ja), s = *(const float2*)(st + ja);
+            const float t0 = a[0] * c.x - a[1] * s.x, t1 = a[1] * c.x + a[0] * s.x;
+            const float t2 = a[2] * c.y - a[3] * s.y, t3 = a[3] * c.y + a[2] * s.y;
+            a[0] = t0; a[1] = t1; a[2] = t2; a[3] = t3;
+        }
+        if (jb < p.half) {
+            const float2 c = *(const float2*)(ct + jb), s = *(const float2*)(st + jb);
+            const float t0 = b[0] * c.x - b[1] * s.x, t1 = b[1] * c.x + b[0] * s.x;
+            const float t2 = b[2] * c.y - b[3] * s.y, t3 = b[3] * c.y + b[2] * s.y;
+            b[0] = t0; b[1] = t1; b[2] = t2; b[3] = t3;
+        }
+    } else {              // half == 64: element i pairs with i + 64
+        const float4 c = *(const float4*)(ct + 4 * l), s = *(const float4*)(st + 4 * l);
+        const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = a[i] * cc[i] - b[i] * ss[i], hi = b[i] * cc[i] + a[i] * ss[i];
+            a[i] = lo;
+            b[i] = hi;
+        }
+    }
+    const uint2 oa = make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+    const uint2 ob = make_uint2(pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
+    bf16_t* dst = is_q ? p.q_out + (int64_t)row * p.q_ld + (int64_t)slot * 128 + 4 * l
+                       : p.kcache + (int64_t)u * p.utt_stride + (int64_t)(slot - p.heads) * p.head_stride +
+                             (int64_t)pos * 128 + 4 * l;
+    *(uint2*)dst = oa;
+    *(uint2*)(dst + 64) = ob;
+}
+
 // ------------------------------------------------------------------ embedding gather / splice
 struct EmbedSrc {
     const bf16_t* table;
@@ -419,7 +490,14 @@ void launch_rmsnorm(float* x, const float* w, bf16_t* out, int rows, int d, floa
 void launch_rope(const RopeParams& p, hipStream_t s) {
     if (p.rows <= 0) return;
     Q3_REQUIRE(p.half % 2 == 0 && p.half <= 64, "rope: rotary half-dim must be even and <= 64");
-    const int64_t waves = (int64_t)p.rows * (p.heads + 2 * p.kv_heads);
+    const int slots = p.heads + 2 * p.kv_heads;
+    if (!p.slab && slots % 4 == 0 && p.ld % 4 == 0 && p.q_ld % 4 == 0 && (p.interleaved || p.half == 64)) {
+        const int64_t waves4 = (int64_t)p.rows * (slots / 4);
+        hipLaunchKernelGGL(rope_rows_kernel, dim3(cdiv(waves4, 4)), dim3(256), 0, s, p);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    const int64_t waves = (int64_t)p.rows * slots;
     hipLaunchKernelGGL(rope_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }

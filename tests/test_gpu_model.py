@@ -46,11 +46,15 @@ def _oracle_run(cfg, ck, audio, max_tokens, embed_scale=True):
     return toks, np.stack(trace), stages
 
 
-@pytest.mark.parametrize("variant", ["default", "rotate_half", "no_embed_scale", "q4", "attn4"])
+@pytest.mark.parametrize("variant", ["default", "rotate_half", "partial_rotary", "partial_rotate_half", "no_embed_scale", "q4",
+                                     "attn4"])
 def test_transcribe_teacher_forced_logits(variant, monkeypatch):
     """Per-step logits under teacher forcing with the oracle's own tokens, every decode path
-    (interleaved / rotate-half RoPE, embed rescale on / off, dense / MLX-q4 weights)."""
-    kw = dict(rotate_half=dict(rope_interleaved=0), no_embed_scale=dict(embed_scale=0), q4=dict(weight_format=1)).get(variant, {})
+    (interleaved / rotate-half RoPE over the whole head or its first 64 channels, embed rescale on / off,
+    dense / MLX-q4 weights)."""
+    kw = dict(rotate_half=dict(rope_interleaved=0), partial_rotary=dict(rotary_dim=64),
+              partial_rotate_half=dict(rope_interleaved=0, rotary_dim=64), no_embed_scale=dict(embed_scale=0),
+              q4=dict(weight_format=1)).get(variant, {})
     if variant == "attn4":      # the large groups' four-wave decode attention (a single utterance would take eight)
         monkeypatch.setenv("Q3ASR_ATTN_WAVES", "4")
     cfg = make_config("tiny", **kw)
