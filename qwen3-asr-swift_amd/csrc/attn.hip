@@ -179,7 +179,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     __shared__ float so[WAVES][GROUP][D];
     __shared__ __attribute__((aligned(16))) bf16_t sq[GROUP][D];  // FUSED: this step's normalised, rotated queries
     __shared__ float snew[2][D];                                  // FUSED: the new key (rotated) and value, bf16-rounded
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: tile indices and loop branches stay scalar
     // (utterance, kv head) work items, strided over the grid: the launcher may cap the grid so that a fixed
     // number of workgroups per CU stream the cache while another stream's kernels share the CUs
     const int items = p.B * p.kv_heads;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
         _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                         \
             VV[k] = __builtin_nontemporal_load((const uint32_t*)(vp_ + k * D));                               \
     }
-#define DA_COMPUTE(KF, VV, T)                                                                                  \
+#define DA_COMPUTE(KF, VV, T, MASK)                                                                               \
     {                                                                                                          \
         const int kv0 = (T) * 16;                                                                              \
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                 \
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KF[ks].v, qf[ks].v, s, 0, 0, 0);                       \
         float sv[4], tmax = -INFINITY;                                                                         \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
-            sv[r] = (kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;                                         \
+            sv[r] = (!(MASK) || kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;                              \
             tmax = fmaxf(tmax, sv[r]);                                                                         \
         }                                                                                                      \
         tmax = rows_max(tmax);                                                                                 \
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
             float ox = o[q][0] * a, oy = o[q][1] * a;                                                          \
             _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                   \
                 const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr[k & 3]), q + 16 * (k >> 2))); \
-                const uint32_t vk = (kv0 + k < len) ? VV[k] : 0u;                                              \
+                const uint32_t vk = (!(MASK) || kv0 + k < len) ? VV[k] : 0u;                                   \
                 ox = fmaf(pk, __uint_as_float(vk << 16), ox);                                                  \
                 oy = fmaf(pk, __uint_as_float(vk & 0xffff0000u), oy);                                          \
             }                                                                                                  \
@@ -306,14 +307,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
             if (li < GROUP) qf[ks].u = *(const uint4*)(p.Q + (int64_t)u * p.q_ld + (kvh * GROUP + li) * D + 32 * ks + 8 * lg);
         }
     }
+    // Every tile that is consumed while another is in flight sits in a block whose loads are unconditional: the
+    // compiler counts outstanding loads per path and, where a load is conditional, waits as if it had not been
+    // issued, i.e. also for the tile that was just requested.  The last tile of a wave has its own copy of the code.
     while (t < ntiles) {
         const int t2 = t + WAVES;
-        if (t2 < ntiles) DA_LOAD(kfB, vvB, t2);
-        DA_COMPUTE(kfA, vvA, t);
-        if (t2 >= ntiles) break;
+        if (t2 >= ntiles) {
+            DA_COMPUTE(kfA, vvA, t, true);
+            break;
+        }
+        DA_LOAD(kfB, vvB, t2);
+        DA_COMPUTE(kfA, vvA, t, false);   // a tile with a successor is full: no key of it lies past len
         const int t3 = t2 + WAVES;
-        if (t3 < ntiles) DA_LOAD(kfA, vvA, t3);
-        DA_COMPUTE(kfB, vvB, t2);
+        if (t3 >= ntiles) {
+            DA_COMPUTE(kfB, vvB, t2, true);
+            break;
+        }
+        DA_LOAD(kfA, vvA, t3);
+        DA_COMPUTE(kfB, vvB, t2, false);
         t = t3;
     }
 #undef DA_LOAD
