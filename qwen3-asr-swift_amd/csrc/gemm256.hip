@@ -44,19 +44,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int wr = uwave >> 2, wc = uwave & 3;
     const int li = lane & 15, lg = lane >> 4;
 
-    // ---- workgroup -> tile: XCD-contiguous remap, then groups of 8 M-tiles share each N-tile ----
-    const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-    int L;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
+    // ---- workgroup -> tiles.  The grid is persistent (launch_o caps it at the CU count, a multiple of 8): this
+    // workgroup computes the tiles of the virtual block indices blockIdx.x, blockIdx.x + gridDim.x, ...  A virtual
+    // index maps to a tile by the XCD-contiguous remap (virtual index & 7 is the XCD the workgroup runs on), then
+    // groups of 8 M-tiles share each N-tile. ----
+    const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8, total = tiles_m * tiles_n;
     constexpr int GROUP = 8;
     const int per_group = GROUP * tiles_n;
-    const int grp = L / per_group, first_m = grp * GROUP;
-    const int gsz = min(GROUP, tiles_m - first_m);
-    const int tm = first_m + (L % per_group) % gsz, tn = (L % per_group) / gsz;
-    const int m0 = tm << 8, n0 = tn << 8;
 
     const int nk_total = (p.K + 63) >> 6;
     const int per = (nk_total + p.ksplit - 1) / p.ksplit;
@@ -66,26 +60,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // q*64 + (t >> 3), slot t & 7, which holds source k-chunk (t & 7) ^ ((row >> 1) & 7). ----
     const int srow = tid >> 3;
     const int koff = ((tid & 7) ^ ((srow >> 1) & 7)) * 8;
-    int a_off[2][2], w_off[2][2];  // [q][unit], in elements
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            // A unit u, LDS row q*64 + srow  <-  tile row q*128 + u*64 + srow   (q = reading wave's row half)
-            const int m = min(m0 + q * 128 + u * 64 + srow, p.M - 1) - m0;
-            a_off[q][u] = (m * (int)p.lda + koff) * 2;
-            // W unit u, LDS row rho = q*64 + srow = wc*32 + j*16 + i  <-  tile row wc*64 + (i>>2)*16 + u*8 + j*4 + (i&3)
-            const int rho = q * 64 + srow, i = rho & 15, j = (rho >> 4) & 1, c = rho >> 5;
-            const int n = min(n0 + c * 64 + (i >> 2) * 16 + u * 8 + j * 4 + (i & 3), p.N - 1) - n0;
-            w_off[q][u] = (n * p.K + koff) * 2;
-        }
-    // Both operands are read through buffer descriptors based at the tile's first row: a load needs the fixed
-    // 32-bit per-lane byte offset above plus a scalar K offset, and no vector ALU work inside the K loop.
+    // Both operands are read through buffer descriptors based at the tile's first row: a load needs a fixed
+    // 32-bit per-lane byte offset plus a scalar K offset, and no vector ALU work inside the K loop.
     // Offsets at or beyond BUF_RANGE read as zero (K tail, and the tiles past the end that keep the load counts
     // uniform).
     constexpr int BUF_RANGE = 0x40000000, BUF_OOB = 0x7f000000;
-    const auto a_rsrc = uniform_buffer(p.A + (int64_t)m0 * p.lda, BUF_RANGE);
-    const auto w_rsrc = uniform_buffer((const bf16_t*)p.W + (int64_t)n0 * p.K, BUF_RANGE);
+    int m0 = 0, n0 = 0, tn = 0;
+    int a_off[2][2], w_off[2][2];  // [q][unit], in bytes
+    __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
+    auto setup = [&](int b) {
+        const int q8 = total >> 3, r8 = total & 7, x = b & 7;
+        const int L = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);
+        const int grp = L / per_group, first_m = grp * GROUP;
+        const int gsz = min(GROUP, tiles_m - first_m);
+        const int tm = first_m + (L % per_group) % gsz;
+        tn = (L % per_group) / gsz;
+        m0 = tm << 8;
+        n0 = tn << 8;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // A unit u, LDS row q*64 + srow  <-  tile row q*128 + u*64 + srow   (q = reading wave's row half)
+                const int m = min(m0 + q * 128 + u * 64 + srow, p.M - 1) - m0;
+                a_off[q][u] = (m * (int)p.lda + koff) * 2;
+                // W unit u, LDS row rho = q*64 + srow = wc*32 + j*16 + i  <-  tile row wc*64 + (i>>2)*16 + u*8 + j*4 + (i&3)
+                const int rho = q * 64 + srow, i = rho & 15, j = (rho >> 4) & 1, c = rho >> 5;
+                const int n = min(n0 + c * 64 + (i >> 2) * 16 + u * 8 + j * 4 + (i & 3), p.N - 1) - n0;
+                w_off[q][u] = (n * p.K + koff) * 2;
+            }
+        a_rsrc = uniform_buffer(p.A + (int64_t)m0 * p.lda, BUF_RANGE);
+        w_rsrc = uniform_buffer((const bf16_t*)p.W + (int64_t)n0 * p.K, BUF_RANGE);
+    };
     const int lds_lane0 = uwave * 64 * 16;
 
     // unit: 0 = A0, 1 = A1, 2 = W0, 3 = W1
@@ -108,6 +114,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int w_rd = (wc * 32 + li) * 128 + ((lg ^ (sw & 3)) << 4) + ((sw >> 2) << 6);
 
     f32x4 acc[2][4][2][2];  // [A unit][fragment][W unit][fragment]
+
+    const int nt = kt1 - kt0;
+    // K tile 0 of a tile complete in buffer 0, three units of its K tile 1 in flight
+    auto prefetch = [&]() {
+        stage(0, 2, kt0); stage(0, 0, kt0); stage(0, 3, kt0); stage(0, 1, kt0);
+        stage(1, 2, kt0 + 1); stage(1, 0, kt0 + 1); stage(1, 3, kt0 + 1);
+    };
+    int vb = blockIdx.x;
+    setup(vb);
+    if (nt > 0) prefetch();
+    for (; vb < total; vb += gridDim.x) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -116,13 +133,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][f][u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nt = kt1 - kt0;
     if (nt > 0) {
-        // prologue: K tile 0 complete in buffer 0, three units of K tile 1 in flight
-        stage(0, 2, kt0); stage(0, 0, kt0); stage(0, 3, kt0); stage(0, 1, kt0);
-        stage(1, 2, kt0 + 1); stage(1, 0, kt0 + 1); stage(1, 3, kt0 + 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // everything outstanding is waited for: the loads requested ahead of the previous tile's epilogue and that
+        // epilogue's own loads and stores (loads and stores do not retire in one order, so no counted wait here)
+        if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // first tile: only its own loads are out
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
 
@@ -190,13 +205,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (wr == 0) __builtin_amdgcn_s_barrier();
     }
 
-    // ---- epilogue: lane (li, lg) owns rows m0 + wr*128 + a*64 + f*16 + li, columns c0 .. c0 + 15 ----
-    const int c0 = n0 + wc * 64 + lg * 16;
+    // The next tile's first loads are requested before this tile's epilogue, which then runs under them (one
+    // workgroup fills the CU, so nothing else would cover the epilogue's memory traffic).
+    const int e_m0 = m0, e_n0 = n0, e_tn = tn;
+    if (vb + (int)gridDim.x < total) {
+        setup(vb + gridDim.x);
+        if (nt > 0) prefetch();
+    }
+
+    // ---- epilogue: lane (li, lg) owns rows e_m0 + wr*128 + a*64 + f*16 + li, columns c0 .. c0 + 15 ----
+    const int c0 = e_n0 + wc * 64 + lg * 16;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const int m = m0 + wr * 128 + a * 64 + f * 16 + li;
+            const int m = e_m0 + wr * 128 + a * 64 + f * 16 + li;
             const bool row_ok = m < p.M;
             int64_t orow = m;
             if (row_ok && p.rowmap) orow = p.rowmap[m];
@@ -220,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
                 }
                 if (row_ok && lg == 0) {
-                    const int part = tn * 4 + wc;
+                    const int part = e_tn * 4 + wc;
                     p.part_val[(int64_t)m * p.nparts + part] = best;
                     p.part_idx[(int64_t)m * p.nparts + part] = bidx;
                 }
@@ -280,6 +303,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 }
             }
         }
+    }
+}
+
+// One workgroup per CU, rounded down to a multiple of 8 so that a workgroup's virtual block indices all map to its XCD.
+int persistent_grid() {
+    static int grid = 0;
+    if (!grid) {
+        int dev = 0, cus = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        grid = std::max(8, cus & ~7);
+    }
+    return grid;
 }
 
 template <int OUT>
@@ -294,7 +330,7 @@ void launch_o(const GemmParams& p, hipStream_t s) {
     if (!name[0]) snprintf(name, sizeof name, "gemm256_kernel<%d>", OUT);
     {
         ProfScope ps(name, 2.0 * p.M * p.N * p.K, s);
-        hipLaunchKernelGGL((gemm256_kernel<OUT>), dim3(tiles, 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
+        hipLaunchKernelGGL((gemm256_kernel<OUT>), dim3(std::min(tiles, persistent_grid()), 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
     }
     HIP_CHECK(hipGetLastError());
 }
