@@ -10,6 +10,7 @@ exists offline); with such weights the decoder never emits EOS, so every clip ru
 full max_tokens = 448 greedy steps -- the most expensive case the reference's loop allows.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
@@ -70,7 +71,7 @@ def pmc_traffic(kernel, args):
     workload counts; anything else reports None."""
     import glob
     if (args.preset != "1.7b" or args.max_tokens != 448 or args.clip_seconds != 30.0 or args.weights != "bf16"
-            or args.workload == "ragged" or args.audio != "speechlike"):
+            or args.workload == "ragged" or args.audio != "speechlike" or args.length_dist != "none"):
         return None, None
     short = kernel.split("<")[0].replace("_kernel", "")
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{short}_b{args.batch}.json")), reverse=True):
@@ -93,6 +94,54 @@ def measured_copy_ceiling(torch, nbytes=1 << 30, reps=10):
     e1.record()
     torch.cuda.synchronize()
     return round(2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
+def rank_envs(n, port, base_env=None):
+    """Environment of each of the n ranks the launcher starts (what torch.distributed's env:// rendezvous reads)."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base_env is None else base_env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        envs.append(e)
+    return envs
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, child=None):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one rank per GPU, before this
+    process has touched the GPU; pass rank 0's result line through; fail if any rank fails."""
+    import subprocess
+    child = child or [sys.executable, os.path.abspath(__file__)]
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    procs = []
+    for r, env in enumerate(rank_envs(n, port)):
+        procs.append(subprocess.Popen(child + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    return 0
+
+
+def scripted_lengths(kind, n, max_tokens, seed):
+    """Tokens each clip emits before its EOS under a labelled synthetic length distribution (random weights never
+    emit EOS on their own).  "u60-150+straggler": U[60, 150] tokens, and one clip of every batch runs to max_tokens."""
+    lo, hi = (int(x) for x in kind.split("+")[0][1:].split("-"))
+    lens = np.random.default_rng(seed).integers(lo, hi + 1, size=n)
+    lens = np.minimum(lens, max_tokens)
+    if kind.endswith("+straggler") and n > 0:
+        lens[n // 2] = max_tokens
+    return lens
 
 
 def main():
@@ -122,7 +171,13 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "q4"], help="q4: MLX affine 4-bit group-quantised decoder weights")
     ap.add_argument("--audio", default="speechlike", choices=["speechlike", "noise"])
     ap.add_argument("--utterances", type=int, default=256, help="ragged workload: recordings per GPU")
+    ap.add_argument("--length-dist", default="none", help="none: every clip decodes until the stop rules or max_tokens end it (with "
+                    "random weights: max_tokens).  uLO-HI[+straggler]: scripted lengths -- clip u stops on an EOS after U[LO, HI] tokens "
+                    "(teacher-forced inputs, the reference's stop rules applied to them), optionally one clip per batch running to max_tokens")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -172,6 +227,13 @@ def main():
         offsets = np.arange(args.batch + 1, dtype=np.int64) * n
         n_units_total = world * args.batch
         what = f"{args.batch} x {args.clip_seconds:g} s synthetic 16 kHz clips per GPU per step"
+    forced = None
+    if args.length_dist != "none":
+        lens_tok = scripted_lengths(args.length_dist, len(piece_ids), args.max_tokens, 99 + rank)
+        forced = np.random.default_rng(7 + rank).integers(1000, 100000, size=(len(piece_ids), args.max_tokens)).astype(np.int32)
+        for u, L in enumerate(lens_tok):
+            if L < args.max_tokens:
+                forced[u, L - 1] = 151645           # <|im_end|>: kept as the clip's last token (Qwen3ASR.swift:571-574)
     dev_audio = torch.from_numpy(np.concatenate(clips)).cuda()
     clips = clips[:1]          # only the CPU baseline still needs a host copy (of one clip)
     if args.workload == "mel":
@@ -187,8 +249,8 @@ def main():
             out.audio_seconds = float(np.minimum(np.diff(offsets), 480000).sum()) / 16000.0
             assert int(frames.min()) > 0
             return out
-        out = model.transcribe_batch(None, 16000, max_tokens=args.max_tokens, stop_rules=not args.no_stop_rules,
-                                     device_audio=(dev_audio.data_ptr(), offsets))
+        out = model.transcribe_batch(None, 16000, max_tokens=args.max_tokens, device_audio=(dev_audio.data_ptr(), offsets),
+                                     stop_rules="forced" if forced is not None else not args.no_stop_rules, forced_tokens=forced)
         if world > 1:
             # the job's one exchange: every rank ends the batch holding every transcript (token ids)
             from q3asr.shard import gather_token_lists
@@ -216,13 +278,17 @@ def main():
 
     audio_s = sum(o.audio_seconds for o in outs)
     tokens = sum(o.tokens_total for o in outs)
-    stats = torch.tensor([dt, audio_s, float(tokens)], dtype=torch.float64, device=coll_dev)
+    row_steps = sum(getattr(o, "decode_rows", 0) for o in outs)
+    stats = torch.tensor([dt, audio_s, float(tokens), float(row_steps)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
-    audio_s, tokens = float(stats[1]), float(stats[2])
+    audio_s, tokens, row_steps = float(stats[1]), float(stats[2]), float(stats[3])
+    lengths = ("every clip runs to max_tokens (random weights never emit EOS)" if args.length_dist == "none" else
+               f"scripted lengths {args.length_dist}: clips stop on a teacher-forced EOS, finished clips leave the decode steps"
+               + (" (retirement off)" if os.environ.get("Q3ASR_RETIRE") == "0" else ""))
 
     n_local = len(piece_ids)
     if args.workload == "mel":
@@ -231,12 +297,12 @@ def main():
     elif args.workload == "ragged":
         metric = f"RTFx (audio s per wall s) node-wide, {args.preset} {args.weights}, 5-300 s recordings in <= 30 s pieces"
         label = (f"Qwen3-ASR-{args.preset} {args.weights} full transcribe (reference stop rules, max_tokens {args.max_tokens}), {what}, "
-                 f"audio resident in HBM, seeded random weights of the true shapes")
+                 f"audio resident in HBM, seeded random weights of the true shapes; {lengths}")
     else:
         metric = ("RTFx (audio s per wall s) node-wide, 1.7B bf16, 30 s clips" if (args.preset, args.weights) == ("1.7b", "bf16")
                   else f"RTFx (audio s per wall s) node-wide, {args.preset} {args.weights}, 30 s clips")
         label = (f"Qwen3-ASR-{args.preset} {args.weights} full transcribe (mel+encoder+prefill+greedy decode, reference stop "
-                 f"rules, max_tokens {args.max_tokens}), {what}, audio resident in HBM, seeded random weights of the true shapes")
+                 f"rules, max_tokens {args.max_tokens}), {what}, audio resident in HBM, seeded random weights of the true shapes; {lengths}")
     if rank == 0 and not prof:
         ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
         print(json.dumps({"metric": metric, "value": round(audio_s / dt, 2),
@@ -269,6 +335,7 @@ def main():
             "dtype": "f32" if args.workload == "mel" else "bf16", "data": "synthetic",
             "config": {"workload": label,
                        "clips_per_gpu": n_local, "tokens_per_clip": round(tokens / (n_units_total * args.steps), 1),
+                       "decode_row_steps_per_clip": round(row_steps / (n_units_total * args.steps), 1),
                        "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}"},
             "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
                          "frac": round(ach / peak, 4), "peak_measured_copy": copy_gbs, "peak_measured_read": read_gbs, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),

@@ -8,8 +8,10 @@
  *
  * Conventions: plain C; every function returns 0 on success and a non-zero code on failure, with a
  * thread-local message available from q3asr_last_error().  The caller owns all buffers it passes;
- * the library owns all device memory it allocates.  A model is immutable after q3asr_finalize and
- * may be driven from one host thread at a time (calls are synchronous, like transcribe).
+ * the library owns all device memory it allocates.  A model's weights are immutable after q3asr_finalize.  Any
+ * number of host threads may call into one model (the reference drives its model from detached tasks,
+ * Qwen3ASR.swift:685-687, RealtimeTranslation.swift:459-477): calls on one model are serialised by the library
+ * and each runs to completion, like the reference's synchronous transcribe; different models run concurrently.
  * "space" arguments say where a caller buffer lives: Q3ASR_HOST or Q3ASR_DEVICE (HIP device memory
  * of the model's GPU).
  */
@@ -70,6 +72,9 @@ int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_
 int q3asr_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t* n_frames, int n_utt, int mel_space,
                  float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space);
 int q3asr_output_length(const q3asr_model* m, int n_frames);
+/* Device memory the model's per-call workspace currently holds (bytes; it is reused across calls and released by
+ * q3asr_destroy).  Counterpart in kind of the reference's resident-memory figure (RuntimeMetrics.swift:9-28). */
+int64_t q3asr_workspace_bytes(q3asr_model* m);
 
 typedef struct q3asr_request {
     const float* audio;          /* concatenated samples */
@@ -80,13 +85,18 @@ typedef struct q3asr_request {
     const int32_t* lang_ids;     /* tokenised " language X<asr_text>" prefixes, concatenated (host) or NULL: Qwen3ASR.swift:302-309 */
     const int32_t* lang_offsets; /* [n_utt + 1] or NULL */
     int max_tokens;              /* Qwen3ASR.swift:64, default 448 */
-    int stop_rules;              /* 1: EOS / control-token / repetition stops of Qwen3ASR.swift:571-627; 0: run max_tokens steps */
-    const int32_t* forced_tokens;/* [n_utt][max_tokens] teacher-forced decoder inputs (parity tests) or NULL */
+    int stop_rules;              /* 1: EOS / control-token / repetition stops of Qwen3ASR.swift:571-627; 0: run max_tokens steps;
+                                    2 (with forced_tokens): the same rules evaluated on the teacher-forced inputs, i.e. scripted stop points */
+    const int32_t* forced_tokens;/* [n_utt][max_tokens] teacher-forced decoder inputs (parity tests) or NULL; the recorded tokens stay
+                                    the model's own choices, and with stop_rules 1 no rule is applied */
     /* debug taps (host pointers, may be NULL) */
     float* tap_logits;           /* [n_utt][tap_steps][vocab] fp32 logits of the first tap_steps steps */
     int tap_steps;
     float* tap_audio_embeds;     /* packed [sum N_u][enc_out_dim] in request order */
     float* tap_inputs_embeds;    /* packed [sum S_u][hidden] spliced prompt embeddings in request order */
+    const float* inject_inputs_embeds; /* debug (host, may be NULL): packed [sum S_u][hidden] rows that replace the spliced prompt
+                                    embeddings, i.e. the decoder is run on given inputsEmbeds (QuantizedTextDecoder.swift:384-446
+                                    takes them as an argument); the prompt's token ids are then never looked up */
 } q3asr_request;
 
 typedef struct q3asr_result {
@@ -97,6 +107,7 @@ typedef struct q3asr_result {
     double ms_mel, ms_encoder, ms_prefill, ms_decode; /* device time per stage (HIP events) */
     int64_t decode_steps;        /* batched decode steps executed */
     int64_t tokens_total;
+    int64_t decode_rows;         /* sum over those steps of the rows computed: an utterance leaves the steps soon after it stops */
 } q3asr_result;
 
 /* Qwen3ASRModel.transcribe up to the token list (Qwen3ASR.swift:60-145; _generateText :170-632):

@@ -41,10 +41,16 @@ int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
     Q3_REQUIRE(cfg->enc_d_model <= 2048 && cfg->hidden <= 2048, "create: model width above 2048 is not supported by the norm kernels");
     Q3_REQUIRE(cfg->rotary_dim > 0 && cfg->rotary_dim % 4 == 0 && cfg->rotary_dim <= cfg->head_dim, "create: rotary_dim must be a multiple of 4 within head_dim");
     Q3_REQUIRE(cfg->weight_format == 0 || cfg->weight_format == 1, "create: unknown weight_format");
+    Q3_REQUIRE(cfg->weight_format == 0 || (cfg->group_size == 64 && cfg->bits == 4),
+               "create: quantised weights must be MLX affine 4-bit with group size 64 (Configuration.swift:67-68)");
+    Q3_REQUIRE(cfg->n_window_infer > 0 && cfg->n_window_infer % (2 * cfg->n_window) == 0, "create: n_window_infer must be a multiple of the chunk length");
+    Q3_REQUIRE(cfg->conv_channels > 0 && cfg->enc_layers > 0 && cfg->layers > 0 && cfg->vocab > 0 && cfg->max_batch >= 0, "create: non-positive size");
     HIP_CHECK(hipSetDevice(device));
     q3asr_model* m = new q3asr_model();
     m->cfg = *cfg;
     m->device = device;
+    if (const char* mb = getenv("Q3ASR_ARENA_BLOCK_MB"))
+        if (atoi(mb) > 0) m->arena.DEFAULT_BLOCK = (size_t)atoi(mb) << 20;
     try {
         HIP_CHECK(hipStreamCreate(&m->stream));
         HIP_CHECK(hipStreamCreate(&m->stream2));
@@ -75,6 +81,7 @@ void q3asr_destroy(q3asr_model* m) {
 int q3asr_load_tensor(q3asr_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* data) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && name && shape && data, "load_tensor: null argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     Q3_REQUIRE(!m->finalized, "load_tensor: model already finalized");
     Q3_REQUIRE(ndim >= 1 && ndim <= 4, "load_tensor: rank must be 1..4");
     Q3_REQUIRE(dtype == Q3ASR_F32 || dtype == Q3ASR_BF16 || dtype == Q3ASR_U32, "load_tensor: unknown dtype");
@@ -95,6 +102,7 @@ int q3asr_load_tensor(q3asr_model* m, const char* name, int dtype, const int64_t
 int q3asr_finalize(q3asr_model* m) {
     Q3_API_BEGIN
     Q3_REQUIRE(m, "finalize: null model");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     model_finalize(m);
     Q3_API_END
 }
@@ -102,6 +110,7 @@ int q3asr_finalize(q3asr_model* m) {
 int q3asr_mel_filterbank(q3asr_model* m, float* out) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && out, "mel_filterbank: null argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     memcpy(out, m->mel.host_fb.data(), m->mel.host_fb.size() * 4);
     Q3_API_END
 }
@@ -110,6 +119,7 @@ int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_
               float* mel_out, int t_stride, int32_t* n_frames, int out_space) {
     Q3_API_BEGIN
     Q3_REQUIRE(m, "mel: null model");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     model_mel(m, audio, offsets, n_utt, sample_rate, audio_space, mel_out, t_stride, n_frames, out_space);
     Q3_API_END
 }
@@ -118,15 +128,23 @@ int q3asr_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t* 
                  float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space) {
     Q3_API_BEGIN
     Q3_REQUIRE(m, "encode: null model");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     model_encode(m, mel, t_stride, n_frames, n_utt, mel_space, embeds_out, out_rows_capacity, cu_tokens, out_space);
     Q3_API_END
 }
 
 int q3asr_output_length(const q3asr_model* m, int n_frames) { return m ? model_output_length(m->cfg, n_frames) : -1; }
 
+int64_t q3asr_workspace_bytes(q3asr_model* m) {
+    if (!m) return -1;
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
+    return (int64_t)m->arena.footprint();
+}
+
 int q3asr_transcribe_tokens(q3asr_model* m, const q3asr_request* req, q3asr_result* res) {
     Q3_API_BEGIN
     Q3_REQUIRE(m, "transcribe: null model");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     model_transcribe(m, req, res);
     Q3_API_END
 }
@@ -134,15 +152,17 @@ int q3asr_transcribe_tokens(q3asr_model* m, const q3asr_request* req, q3asr_resu
 int q3asr_profile_start(q3asr_model* m, int stride) {
     Q3_API_BEGIN
     Q3_REQUIRE(m, "profile_start: null model");
-    prof_start(m->stream, stride);
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
+    prof_start(m->stream, m->stream2, stride);
     Q3_API_END
 }
 
 int q3asr_profile_stop(q3asr_model* m, char* json_out, int capacity) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && json_out && capacity > 2, "profile_stop: null argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     HIP_CHECK(hipSetDevice(m->device));
-    const std::string j = prof_stop();
+    const std::string j = prof_stop(m->stream);
     Q3_REQUIRE((int)j.size() + 1 <= capacity, "profile_stop: buffer too small");
     memcpy(json_out, j.c_str(), j.size() + 1);
     Q3_API_END
@@ -153,6 +173,7 @@ int q3asr_op_gemm(q3asr_model* m, const uint16_t* a, const uint16_t* w, const fl
                   int tile, int ksplit, float* out) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && a && w && out, "op_gemm: null argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     HIP_CHECK(hipSetDevice(m->device));
     m->arena.reset();
     bf16_t* da = m->arena.get<bf16_t>((size_t)M * K);
@@ -190,6 +211,7 @@ int q3asr_op_greedy_rules(q3asr_model* m, const int32_t* picks, const int32_t* s
                           int stop_rules, int32_t* tokens_out, int32_t* n_tokens_out) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && picks && tokens_out && n_tokens_out && n_utt > 0 && steps > 0 && max_tokens > 0, "op_greedy_rules: bad argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     HIP_CHECK(hipSetDevice(m->device));
     m->arena.reset();
     const size_t B = (size_t)n_utt;
@@ -215,6 +237,7 @@ int q3asr_op_greedy_rules(q3asr_model* m, const int32_t* picks, const int32_t* s
 int q3asr_op_read_bandwidth(q3asr_model* m, int64_t bytes, float* gb_per_s) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && gb_per_s && bytes >= (1 << 20) && bytes % 16 == 0, "op_read_bandwidth: bad argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     HIP_CHECK(hipSetDevice(m->device));
     m->arena.reset();
     char* buf = m->arena.get<char>((size_t)bytes);
@@ -231,6 +254,7 @@ int q3asr_op_read_bandwidth(q3asr_model* m, int64_t bytes, float* gb_per_s) {
 int q3asr_op_mfma_f32_rate(q3asr_model* m, int waves_per_simd, int iters, float* tflops) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && tflops && iters > 0 && (waves_per_simd == 1 || waves_per_simd == 2), "op_mfma_f32_rate: bad argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     HIP_CHECK(hipSetDevice(m->device));
     m->arena.reset();
     *tflops = mfma_f32_probe_tflops(m->arena.get<float>(4), waves_per_simd, iters, m->stream);
@@ -240,6 +264,7 @@ int q3asr_op_mfma_f32_rate(q3asr_model* m, int waves_per_simd, int iters, float*
 int q3asr_op_gemm_time(q3asr_model* m, int M, int N, int K, int tile, int ksplit, int out_kind, int iters, float* ms_per_call) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && ms_per_call && iters > 0 && out_kind >= 0 && out_kind <= 5, "op_gemm_time: bad argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     HIP_CHECK(hipSetDevice(m->device));
     m->arena.reset();
     const int ks = std::max(1, ksplit);
@@ -279,6 +304,7 @@ int q3asr_op_gemm_q4(q3asr_model* m, const uint16_t* a, const uint32_t* wq, cons
                      int M, int N, int K, int tile, float* out) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && a && wq && scales && biases && out, "op_gemm_q4: null argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     HIP_CHECK(hipSetDevice(m->device));
     m->arena.reset();
     bf16_t* da = m->arena.get<bf16_t>((size_t)M * K);
@@ -303,6 +329,7 @@ int q3asr_op_attention(q3asr_model* m, const uint16_t* q, const uint16_t* k, con
                        int n_seq, int heads, int group, int head_dim, int causal, uint16_t* out) {
     Q3_API_BEGIN
     Q3_REQUIRE(m && q && k && v && cu_seqlens && out && n_seq > 0, "op_attention: null argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
     Q3_REQUIRE(group > 0 && heads % group == 0, "op_attention: heads must be a multiple of group");
     HIP_CHECK(hipSetDevice(m->device));
     m->arena.reset();

@@ -42,16 +42,21 @@ struct DecodeRopeIn {
     int half = 0, interleaved = 0, max_pos = 0;
 };
 
+// The step's B rows belong to utterances slot[0..B) (null: row r is utterance r).  Q, O and the raw projections
+// are indexed by row; the cache, lens and done by utterance.
 struct DecodeAttnParams {
-    const bf16_t* Q; int64_t q_ld;          // Q[u][head*D + d] (already normalised + rotated)
+    const bf16_t* Q; int64_t q_ld;          // Q[row][head*D + d] (already normalised + rotated)
     const bf16_t* K; const bf16_t* V;       // cache[u*utt_stride + kvhead*head_stride + pos*D + d]
     int64_t utt_stride, head_stride;
     const int* lens; int len_add;           // keys visible to utterance u = lens[u] + len_add
     bf16_t* O; int64_t o_ld;
     int B, kv_heads, group;
     float scale;
-    int max_blocks = 0;                     // > 0: at most this many workgroups, each looping over (utterance, head) items
+    int max_blocks = 0;                     // > 0: at most this many workgroups, each looping over (row, head) items
     DecodeRopeIn rope;                      // set: Q is ignored, K/V are appended in place (len_add must be 0)
+    const int* slot = nullptr;              // [B] row -> utterance
+    const int* done = nullptr;              // [utt] non-zero: the utterance has stopped (Qwen3ASR.swift:571-574): its cache is
+                                            // neither read nor appended to, its output rows are zero
 };
 // work: algorithmic K/V bytes of the launch (profiling only)
 void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, double work = 0);

@@ -185,7 +185,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     // number of workgroups per CU stream the cache while another stream's kernels share the CUs
     const int items = p.B * p.kv_heads;
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    const int u = item % p.B, kvh = item / p.B;
+    const int row = item % p.B, kvh = item / p.B;
+    const int u = p.slot ? p.slot[row] : row;
+    if (p.done && p.done[u]) {   // workgroup-uniform: a stopped utterance costs no cache traffic
+        for (int idx = tid; idx < GROUP * D / 2; idx += 64 * WAVES)
+            *(uint32_t*)(p.O + (int64_t)row * p.o_ld + (kvh * GROUP) * D + 2 * idx) = 0u;
+        continue;
+    }
     // FUSED: len counts the keys already cached; the new one is handled from LDS after the loop
     const int len = p.lens[u] + (FUSED ? 0 : p.len_add);
     const bf16_t* Kb = p.K + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
         const RopeTables tabs{r.cos_tab, r.sin_tab, r.half, r.interleaved, r.max_pos};
         for (int sl = wave; sl < GROUP + 2; sl += WAVES) {
             const int col = sl < GROUP ? (kvh * GROUP + sl) * D : (sl == GROUP ? (heads + kvh) * D : (heads + p.kv_heads + kvh) * D);
-            const int64_t src = (int64_t)u * r.ld + col + 2 * lane;
+            const int64_t src = (int64_t)row * r.ld + col + 2 * lane;
             float x0, x1;
             uint32_t raw;
             if (r.slab) {
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             qf[ks].u = make_uint4(0, 0, 0, 0);
-            if (li < GROUP) qf[ks].u = *(const uint4*)(p.Q + (int64_t)u * p.q_ld + (kvh * GROUP + li) * D + 32 * ks + 8 * lg);
+            if (li < GROUP) qf[ks].u = *(const uint4*)(p.Q + (int64_t)row * p.q_ld + (kvh * GROUP + li) * D + 32 * ks + 8 * lg);
         }
     }
     // Every tile that is consumed while another is in flight sits in a block whose loads are unconditional: the
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
             L += sm_l[w][q] * f;
             O += so[w][q][d] * f;
         }
-        p.O[(int64_t)u * p.o_ld + (kvh * GROUP + q) * D + d] = f32_to_bf16(O / L);
+        p.O[(int64_t)row * p.o_ld + (kvh * GROUP + q) * D + d] = f32_to_bf16(O / L);
     }
     __syncthreads();  // the merge buffers are reused by the next item
     }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <stdexcept>
 
@@ -58,3 +59,19 @@ __device__ __forceinline__ float wave_max(float v) {
 #endif
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// One-time set-up per HIP device (function attributes, device properties): several models on several devices and
+// several host threads may reach a launcher at once.  A set-up that throws is retried by the next caller.
+struct PerDeviceOnce {
+    static constexpr int MAX_DEVICES = 64;
+    std::once_flag flags[MAX_DEVICES];
+    template <class F>
+    void run(F&& fn) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        Q3_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device ordinal above 63");
+        std::call_once(flags[dev], fn);
+    }
+};
+// Compute units of the current device.
+int device_cus();

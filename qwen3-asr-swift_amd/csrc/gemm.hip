@@ -350,16 +350,15 @@ void launch_t(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const size_t lds = (size_t)gemm_stages(MT, NT) * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    once.run([&] {
         HIP_CHECK(hipFuncSetAttribute((const void*)gemm_kernel<MT, NT, AMODE, OUT, WFMT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    static char name[64];
-    if (!name[0]) snprintf(name, sizeof name, "gemm_kernel<%d,%d,%d,%d,%d>", MT, NT, AMODE, OUT, WFMT);
+    });
+    static const std::string name = "gemm_kernel<" + std::to_string(MT) + "," + std::to_string(NT) + "," + std::to_string(AMODE) + "," +
+                                    std::to_string(OUT) + "," + std::to_string(WFMT) + ">";
     {
-        ProfScope ps(name, 2.0 * p.M * p.N * p.K, s);
+        ProfScope ps(name.c_str(), 2.0 * p.M * p.N * p.K, s);
         hipLaunchKernelGGL((gemm_kernel<MT, NT, AMODE, OUT, WFMT>), dim3(tiles, 1, p.ksplit), dim3(256), lds, s, p);
     }
     HIP_CHECK(hipGetLastError());

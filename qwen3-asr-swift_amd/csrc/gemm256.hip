@@ -307,29 +307,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 }
 
 // One workgroup per CU, rounded down to a multiple of 8 so that a workgroup's virtual block indices all map to its XCD.
-int persistent_grid() {
-    static int grid = 0;
-    if (!grid) {
-        int dev = 0, cus = 0;
-        HIP_CHECK(hipGetDevice(&dev));
-        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        grid = std::max(8, cus & ~7);
-    }
-    return grid;
-}
+int persistent_grid() { return std::max(8, device_cus() & ~7); }
 
 template <int OUT>
 void launch_o(const GemmParams& p, hipStream_t s) {
     const int tiles = cdiv(p.M, 256) * cdiv(p.N, 256);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
-    static char name[64];
-    if (!name[0]) snprintf(name, sizeof name, "gemm256_kernel<%d>", OUT);
+    static PerDeviceOnce once;
+    once.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); });
+    static const std::string name = "gemm256_kernel<" + std::to_string(OUT) + ">";
     {
-        ProfScope ps(name, 2.0 * p.M * p.N * p.K, s);
+        ProfScope ps(name.c_str(), 2.0 * p.M * p.N * p.K, s);
         hipLaunchKernelGGL((gemm256_kernel<OUT>), dim3(std::min(tiles, persistent_grid()), 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
     }
     HIP_CHECK(hipGetLastError());

@@ -467,13 +467,9 @@ void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, d
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
                 const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work) {
     if (n_tiles <= 0) return;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        HIP_CHECK(hipGetDevice(&dev));
-        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES));
-    }
+    static PerDeviceOnce once;
+    once.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES)); });
+    const int cus = device_cus();
     ProfScope ps("mel_kernel", work, s);
     // one workgroup fits per CU (142 KB of LDS); each loops over its share of the tiles
     hipLaunchKernelGGL(mel_kernel, dim3(std::min(n_tiles, cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,

@@ -40,9 +40,14 @@ struct DecLayerW {
     LinearW qkv, o, gate_up, down;
 };
 
-// Bump allocator over a growing list of device blocks.  Blocks persist across calls, so a steady
-// stream of equally shaped batches allocates nothing after the first one.
+// Bump allocator over a list of device blocks.  Blocks persist across calls, so a steady stream of equally
+// shaped batches allocates nothing after the first one.  Requests above the default block size get a block of
+// their own (the KV cache is one such request of up to ~100 GB); when a later call asks for a slightly larger one,
+// the idle block that has become too small is released first instead of being kept beside its replacement, and an
+// out-of-memory answer releases every idle block before the one retry.  Within a call blocks are never erased
+// from the list (marks hold indices): a released block stays as an empty entry until the next call's reset.
 struct BlockArena {
+    size_t DEFAULT_BLOCK = (size_t)1 << 30;   // Q3ASR_ARENA_BLOCK_MB overrides it (tests reach the large-request path with small models)
     struct Block {
         char* p;
         size_t cap, off;
@@ -53,8 +58,11 @@ struct BlockArena {
         size_t cur;
         std::vector<size_t> offs;
     };
-    void reset() {
-        for (auto& b : blocks) b.off = 0;
+    void reset() {   // start of a call: every block is idle, marks of earlier calls are void
+        size_t n = 0;
+        for (auto& b : blocks)
+            if (b.p) blocks[n++] = Block{b.p, b.cap, 0};
+        blocks.resize(n);
         cur = 0;
     }
     Mark mark() const {
@@ -66,23 +74,46 @@ struct BlockArena {
         cur = k.cur;
         for (size_t i = 0; i < blocks.size(); ++i) blocks[i].off = i < k.offs.size() ? k.offs[i] : 0;
     }
+    size_t footprint() const {
+        size_t n = 0;
+        for (auto& b : blocks) n += b.cap;
+        return n;
+    }
+    // hipFree waits for the device, so memory of an idle block that earlier kernels of this call still read
+    // (handed out before a restore) is not pulled from under them.
+    void drop(Block& b) {
+        if (b.p) (void)hipFree(b.p);
+        b = Block{nullptr, 0, 0};
+    }
     template <class T>
     T* get(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
         if (bytes == 0) bytes = 256;
         while (cur < blocks.size() && blocks[cur].off + bytes > blocks[cur].cap) ++cur;
         if (cur == blocks.size()) {
-            const size_t cap = bytes > ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
+            const size_t cap = bytes > DEFAULT_BLOCK ? bytes : DEFAULT_BLOCK;
+            if (bytes > DEFAULT_BLOCK)   // idle blocks of the large kind that this request has outgrown
+                for (auto& b : blocks)
+                    if (b.p && b.off == 0 && b.cap > DEFAULT_BLOCK && b.cap < bytes) drop(b);
             void* p = nullptr;
-            HIP_CHECK(hipMalloc(&p, cap));
-            blocks.push_back({(char*)p, cap, 0});
+            hipError_t e = hipMalloc(&p, cap);
+            if (e == hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                for (auto& b : blocks)
+                    if (b.p && b.off == 0) drop(b);
+                e = hipMalloc(&p, cap);
+            }
+            if (e != hipSuccess)
+                throw Q3Error(std::string("q3asr: workspace allocation of ") + std::to_string(cap >> 20) + " MiB failed: " + hipGetErrorString(e));
+            blocks.push_back(Block{(char*)p, cap, 0});   // cur == the new block: the scan above ran off the end
         }
         T* r = (T*)(blocks[cur].p + blocks[cur].off);
         blocks[cur].off += bytes;
         return r;
     }
     void release() {
-        for (auto& b : blocks) (void)hipFree(b.p);
+        for (auto& b : blocks)
+            if (b.p) (void)hipFree(b.p);
         blocks.clear();
         cur = 0;
     }
@@ -91,6 +122,10 @@ struct BlockArena {
 struct q3asr_model {
     q3asr_config cfg;
     int device = 0;
+    // Calls on one model are serialised: they share its streams and workspace.  Several host threads may call
+    // (the reference's model is driven from detached tasks, Qwen3ASR.swift:685-687, RealtimeTranslation.swift:459-477);
+    // each call runs alone and to completion, like the reference's synchronous transcribe.
+    std::mutex call_mutex;
     hipStream_t stream = nullptr;
     bool finalized = false;
     std::map<std::string, HostTensor> host;  // checkpoint tensors until finalize

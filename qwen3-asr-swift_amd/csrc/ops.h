@@ -72,8 +72,8 @@ struct SpliceParams {
 };
 void launch_splice(const SpliceParams& p, hipStream_t s);
 
-// Token embedding for the decode step: hidden[u] = table[next_tok[u]].
-void launch_embed_tokens(const int* tok, int B, int hidden, const bf16_t* table, const uint32_t* qw, const bf16_t* qs,
+// Token embedding for the decode step: hidden[r] = table[next_tok[slot ? slot[r] : r]].
+void launch_embed_tokens(const int* tok, const int* slot, int B, int hidden, const bf16_t* table, const uint32_t* qw, const bf16_t* qs,
                          const bf16_t* qb, int qgroup, float* out, hipStream_t s);
 
 // Final reduction of the LM-head argmax partials: lowest index among equal maxima.
@@ -81,18 +81,26 @@ void launch_argmax_reduce(const float* part_val, const int* part_idx, int nparts
 // Plain argmax over fp32 logits rows (debug tap path).
 void launch_argmax_rows(const float* logits, int rows, int n, int* out, hipStream_t s);
 
-// Greedy-loop bookkeeping and stop rules (Qwen3ASR.swift:567-627), one thread per utterance.
+// Greedy-loop bookkeeping and stop rules (Qwen3ASR.swift:567-627), one thread per row of the step.
+// The step's B rows belong to utterances slot[0..B) (null: row r is utterance r); every per-utterance array
+// is indexed by utterance.  The reference stops computing for a clip the moment it stops (:571-574, batch 1);
+// here the kernel also writes the utterances still running, in row order, to live_out, so that the host can
+// drop the finished rows from the next steps by switching to that list.
 struct StepParams {
-    const int* argmax;   // [B] token chosen by this step
-    int* tokens;         // [B][max_tokens]
-    int* ntok;           // [B]
-    int* done;           // [B]
-    int* seen_asr;       // [B]
-    int* next_tok;       // [B] token fed to the next step
-    int* cur_len;        // [B] keys in the cache; incremented when advance != 0
+    const int* argmax;   // [B] token chosen by this step, per row
+    int* tokens;         // [utt][max_tokens]
+    int* ntok;           // [utt]
+    int* done;           // [utt]
+    int* seen_asr;       // [utt]
+    int* next_tok;       // [utt] token fed to the next step
+    int* cur_len;        // [utt] keys in the cache; incremented when advance != 0
     int* n_active;       // [1] utterances still running after this step
-    const int* forced;   // [B][max_tokens] teacher-forced inputs or null
-    int B, max_tokens, advance, stop_rules;
+    const int* forced;   // [utt][max_tokens] teacher-forced inputs or null
+    int B, max_tokens, advance;
+    int stop_rules;      // 0: none; 1: the reference's rules on the generated tokens; 2: on the teacher-forced inputs
+    const int* slot = nullptr;    // [B] row -> utterance
+    int* live_out = nullptr;      // [<= B] utterances still running after this step, in row order (optional)
+    long long* keys_out = nullptr;  // [1] sum over those utterances of the keys their next step attends (optional)
 };
 void launch_step(const StepParams& p, hipStream_t s);
 

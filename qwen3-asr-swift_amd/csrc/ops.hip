@@ -339,12 +339,13 @@ __global__ __launch_bounds__(256) void splice_kernel(SpliceParams p, EmbedSrc e)
     ((float4*)(p.hidden_out + (int64_t)row * p.hidden))[c] = v;
 }
 
-__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict__ tok, int B, EmbedSrc e, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict__ tok, const int* __restrict__ slot, int B, EmbedSrc e,
+                                                           float* __restrict__ out) {
     const int h4 = e.hidden >> 2;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)B * h4) return;
-    const int u = (int)(idx / h4), c = (int)(idx % h4);
-    ((float4*)(out + (int64_t)u * e.hidden))[c] = embed4(e, tok[u], 4 * c);
+    const int r = (int)(idx / h4), c = (int)(idx % h4);
+    ((float4*)(out + (int64_t)r * e.hidden))[c] = embed4(e, tok[slot ? slot[r] : r], 4 * c);
 }
 
 // ------------------------------------------------------------------ argmax
@@ -387,52 +388,80 @@ constexpr int TOK_IM_START = 151644, TOK_IM_END = 151645, TOK_ENDOFTEXT = 151643
 constexpr int TOK_AUDIO_START = 151669, TOK_AUDIO_END = 151670, TOK_AUDIO_PAD = 151676, TOK_ASR_TEXT = 151704;
 
 __global__ __launch_bounds__(256) void step_kernel(StepParams p) {
-    __shared__ int active;
-    if (threadIdx.x == 0) active = 0;
-    __syncthreads();
-    for (int u = threadIdx.x; u < p.B; u += 256) {
-        if (!p.done[u]) {
-            const int tok = p.argmax[u];
-            int* toks = p.tokens + (int64_t)u * p.max_tokens;
-            int n = p.ntok[u];
-            toks[n++] = tok;
-            p.ntok[u] = n;
-            bool stop = false;
-            if (p.stop_rules) {
-                const int seen = p.seen_asr[u];
-                // breaks evaluated right after the append: Qwen3ASR.swift:597-627.  They sit inside the decode loop,
-                // so the prefill's token (:388-389, advance == 0 here) is appended without them.
-                const bool in_loop = p.advance != 0;
-                if (in_loop && (tok == TOK_IM_START || tok == TOK_AUDIO_START || tok == TOK_AUDIO_END || tok == TOK_AUDIO_PAD)) stop = true;
-                if (!stop && in_loop && seen && n >= 32) {
-                    int run = 0;
-                    for (int i = n - 1; i >= 0 && toks[i] == tok; --i) ++run;
-                    if (run >= 16) stop = true;
-                }
-                if (!stop && in_loop && seen && n >= 64) {
-                    int uniq[5], nu = 0;
-                    for (int i = n - 64; i < n && nu <= 4; ++i) {
-                        bool found = false;
-                        for (int k = 0; k < nu; ++k) found |= (uniq[k] == toks[i]);
-                        if (!found) uniq[nu++] = toks[i];
+    __shared__ int wave_cnt[4];
+    __shared__ long long wave_keys[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;            // running utterances found in the rows before this pass (same in every thread)
+    long long keys = 0;
+    for (int r0 = 0; r0 < p.B; r0 += 256) {
+        const int r = r0 + tid;
+        bool live = false;
+        int u = 0;
+        if (r < p.B) {
+            u = p.slot ? p.slot[r] : r;
+            if (!p.done[u]) {
+                const int tok = p.argmax[r];
+                int* toks = p.tokens + (int64_t)u * p.max_tokens;
+                int n = p.ntok[u];
+                toks[n++] = tok;
+                p.ntok[u] = n;
+                bool stop = false;
+                if (p.stop_rules) {
+                    // mode 2: the loop's control flow follows the teacher-forced inputs (scripted stop points), as if
+                    // each forced token had been the step's choice
+                    const int* hist = p.stop_rules == 2 ? p.forced + (int64_t)u * p.max_tokens : toks;
+                    const int rt = hist[n - 1];
+                    const int seen = p.seen_asr[u];
+                    // breaks evaluated right after the append: Qwen3ASR.swift:597-627.  They sit inside the decode loop,
+                    // so the prefill's token (:388-389, advance == 0 here) is appended without them.
+                    const bool in_loop = p.advance != 0;
+                    if (in_loop && (rt == TOK_IM_START || rt == TOK_AUDIO_START || rt == TOK_AUDIO_END || rt == TOK_AUDIO_PAD)) stop = true;
+                    if (!stop && in_loop && seen && n >= 32) {
+                        int run = 0;
+                        for (int i = n - 1; i >= 0 && hist[i] == rt; --i) ++run;
+                        if (run >= 16) stop = true;
                     }
-                    if (nu <= 4) stop = true;
+                    if (!stop && in_loop && seen && n >= 64) {
+                        int uniq[5], nu = 0;
+                        for (int i = n - 64; i < n && nu <= 4; ++i) {
+                            bool found = false;
+                            for (int k = 0; k < nu; ++k) found |= (uniq[k] == hist[i]);
+                            if (!found) uniq[nu++] = hist[i];
+                        }
+                        if (nu <= 4) stop = true;
+                    }
+                    // checks made at the top of the next iteration: :571-578
+                    if (!stop) {
+                        if (rt == TOK_IM_END || rt == TOK_ENDOFTEXT) stop = true;
+                        else if (rt == TOK_ASR_TEXT) p.seen_asr[u] = 1;
+                    }
                 }
-                // checks made at the top of the next iteration: :571-578
-                if (!stop) {
-                    if (tok == TOK_IM_END || tok == TOK_ENDOFTEXT) stop = true;
-                    else if (tok == TOK_ASR_TEXT) p.seen_asr[u] = 1;
-                }
+                if (n >= p.max_tokens) stop = true;
+                p.next_tok[u] = p.forced ? p.forced[(int64_t)u * p.max_tokens + n - 1] : tok;
+                if (stop) p.done[u] = 1;
+                live = !stop;
+                if (p.advance) p.cur_len[u] += 1;
             }
-            if (n >= p.max_tokens) stop = true;
-            p.next_tok[u] = p.forced ? p.forced[(int64_t)u * p.max_tokens + n - 1] : tok;
-            if (stop) p.done[u] = 1;
-            else atomicAdd(&active, 1);
-            if (p.advance) p.cur_len[u] += 1;
         }
+        // ordered compaction of the running utterances: ballot within a wave, wave totals through LDS
+        const unsigned long long mask = __ballot(live);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        long long k = live ? (long long)p.cur_len[u] + 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
+        if (lane == 0) { wave_cnt[wave] = __popcll(mask); wave_keys[wave] = k; }
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (live && p.live_out) p.live_out[off + before] = u;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        keys += wave_keys[0] + wave_keys[1] + wave_keys[2] + wave_keys[3];
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) *p.n_active = active;
+    if (tid == 0) {
+        *p.n_active = base;
+        if (p.keys_out) *p.keys_out = keys;
+    }
 }
 
 __global__ __launch_bounds__(256) void swiglu_reduce_kernel(const float* __restrict__ slab, int nslab, int64_t slab_stride,
@@ -515,11 +544,11 @@ void launch_splice(const SpliceParams& p, hipStream_t s) {
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_embed_tokens(const int* tok, int B, int hidden, const bf16_t* table, const uint32_t* qw, const bf16_t* qs,
+void launch_embed_tokens(const int* tok, const int* slot, int B, int hidden, const bf16_t* table, const uint32_t* qw, const bf16_t* qs,
                          const bf16_t* qb, int qgroup, float* out, hipStream_t s) {
     if (B <= 0) return;
     EmbedSrc e{table, qw, qs, qb, qgroup, hidden};
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv((int64_t)B * (hidden / 4), 256)), dim3(256), 0, s, tok, B, e, out);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv((int64_t)B * (hidden / 4), 256)), dim3(256), 0, s, tok, slot, B, e, out);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -537,6 +566,7 @@ void launch_argmax_rows(const float* logits, int rows, int n, int* out, hipStrea
 
 void launch_step(const StepParams& p, hipStream_t s) {
     if (p.B <= 0) return;
+    Q3_REQUIRE(p.stop_rules != 2 || p.forced, "step: stop rules on the forced inputs need forced inputs");
     hipLaunchKernelGGL(step_kernel, dim3(1), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }

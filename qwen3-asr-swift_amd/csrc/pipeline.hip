@@ -328,15 +328,64 @@ void model_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t*
 // ------------------------------------------------------------------------------------------ transcribe
 namespace {
 
-// The decode-step projections run b rows against wide weights, where the best (tile, split-K)
-// pair depends on b and on the projection's shape.  Once per batch size, every candidate is timed on
-// layer 0's own weights with pseudo-random activations, and a split is charged for its partial-sum
-// slabs (written once, read once by the consumer kernel).  Q3ASR_DECODE_TILE / Q3ASR_DECODE_SPLIT
-// pin one candidate for tuning runs.
-q3asr_model::DecodePlan decode_plan(Ctx& c, int b, GemmWFmt wf) {
+// The decode-step projections run `rows` rows against wide weights, where the best (tile, split-K) pair depends
+// on the row count and on the projection's shape.  The plan is a fixed function of (rows, N, K, weight format),
+// evaluated per power-of-two bucket of the row count, so that equal requests are computed by equal kernels in
+// every process and on every rank (the reference is deterministic for a given input).  All unsplit variants
+// accumulate K in the same order with the same MFMA, so the tile never changes a result; the split count and the
+// fused-versus-slab form do (within the bf16 tolerance).  Q3ASR_DECODE_TILE / _SPLIT / _NO_FUSE pin one variant;
+// Q3ASR_DECODE_AUTOTUNE=1 replaces the rule by a measurement of every candidate on layer 0's weights (tuning runs).
+int plan_bucket(int rows) {
+    int b = 8;
+    while (b < rows) b <<= 1;
+    return b;
+}
+
+void tile_dims(int tile, int& bm, int& bn) {
+    bm = tile == 3 ? 256 : (tile == 1 ? 64 : 128);
+    bn = tile == 3 ? 256 : (tile == 0 ? 128 : 64);
+}
+
+q3asr_model::DecodePlan decode_plan_rule(const q3asr_model* m, int rows, GemmWFmt wf) {
+    const DecLayerW& L = m->dec[0];
+    const LinearW* W[4] = {&L.qkv, &L.o, &L.gate_up, &L.down};
+    q3asr_model::DecodePlan plan;
+    const char* env_tile = getenv("Q3ASR_DECODE_TILE");
+    const char* env_split = getenv("Q3ASR_DECODE_SPLIT");
+    const bool allow_fused = !getenv("Q3ASR_DECODE_NO_FUSE");
+    const int R = plan_bucket(rows);
+    for (int g = 0; g < 4; ++g) {
+        const int N = W[g]->N, K = W[g]->K, ktiles = K / 64;
+        // the largest tile that still gives every CU a workgroup without splitting; otherwise the tile that wastes the
+        // fewest rows, split along K until about 256 workgroups stream the weights (at least four K tiles per split)
+        int tile = -1, ks = 1;
+        for (int t : {3, 0, 2, 1}) {
+            if (t == 3 && (wf != W_BF16 || R <= 128)) continue;
+            if (t == 1 && (R > 512 || g == 2)) continue;   // no SwiGLU epilogue on the 64x64 tile
+            int bm, bn;
+            tile_dims(t, bm, bn);
+            if ((int64_t)cdiv(R, bm) * cdiv(N, bn) >= (t == 3 ? 192 : 256)) { tile = t; break; }
+        }
+        if (tile < 0) {
+            tile = R <= 64 && g != 2 ? 1 : 2;
+            int bm, bn;
+            tile_dims(tile, bm, bn);
+            const int64_t wgs = (int64_t)cdiv(R, bm) * cdiv(N, bn);
+            while (ks < 8 && wgs * ks < 256 && ktiles / (ks * 2) >= 4) ks *= 2;
+        }
+        if (env_tile) tile = atoi(env_tile);
+        if (env_split) ks = std::max(1, atoi(env_split));   // "0" asks for the fused form, "1" for one slab
+        const bool fused = ks == 1 && allow_fused && !(env_split && atoi(env_split) != 0);
+        if (tile == 1 && g == 2 && fused) tile = 2;
+        plan.tile[g] = tile;
+        plan.ks[g] = ks;
+        plan.fused[g] = fused;
+    }
+    return plan;
+}
+
+q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
     q3asr_model* m = c.m;
-    const auto hit = m->decode_plans.find(b);
-    if (hit != m->decode_plans.end()) return hit->second;
     const DecLayerW& L = m->dec[0];
     const LinearW* W[4] = {&L.qkv, &L.o, &L.gate_up, &L.down};
     q3asr_model::DecodePlan plan;
@@ -391,11 +440,22 @@ q3asr_model::DecodePlan decode_plan(Ctx& c, int b, GemmWFmt wf) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     m->arena.restore(mark);
+    return plan;
+}
+
+q3asr_model::DecodePlan decode_plan(Ctx& c, int rows, GemmWFmt wf) {
+    q3asr_model* m = c.m;
+    const int bucket = plan_bucket(rows);
+    const auto hit = m->decode_plans.find(bucket);
+    if (hit != m->decode_plans.end()) return hit->second;
+    const char* env_auto = getenv("Q3ASR_DECODE_AUTOTUNE");
+    const bool measured = env_auto && atoi(env_auto) != 0;
+    const q3asr_model::DecodePlan plan = measured ? decode_plan_measured(c, rows, wf) : decode_plan_rule(m, rows, wf);
     if (getenv("Q3ASR_VERBOSE"))
-        fprintf(stderr, "q3asr: decode plan for %d rows (tile/split, split 0 = fused epilogue): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n",
-                b, plan.tile[0], plan.fused[0] ? 0 : plan.ks[0], plan.tile[1], plan.fused[1] ? 0 : plan.ks[1], plan.tile[2],
-                plan.fused[2] ? 0 : plan.ks[2], plan.tile[3], plan.fused[3] ? 0 : plan.ks[3]);
-    m->decode_plans[b] = plan;
+        fprintf(stderr, "q3asr: decode plan for up to %d rows%s (tile/split, split 0 = fused epilogue): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n",
+                bucket, measured ? " (measured)" : "", plan.tile[0], plan.fused[0] ? 0 : plan.ks[0], plan.tile[1], plan.fused[1] ? 0 : plan.ks[1],
+                plan.tile[2], plan.fused[2] ? 0 : plan.ks[2], plan.tile[3], plan.fused[3] ? 0 : plan.ks[3]);
+    m->decode_plans[bucket] = plan;
     return plan;
 }
 
@@ -493,6 +553,12 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
     int* st_len = c.up(utt_rows);
     int* st_active = c.get<int>(64);
     int* st_argmax = c.get<int>(b);
+    // row -> utterance of the current decode rows, and the list the latest step wrote (ping-pong)
+    std::vector<int> ident(b);
+    std::iota(ident.begin(), ident.end(), 0);
+    int* st_map[2] = {c.up(ident), c.get<int>(b)};
+    long long* st_keys = c.get<long long>((size_t)2 * (max_tokens + 2));  // per half and step: keys the step's attention covers
+    HIP_CHECK(hipMemsetAsync(st_keys, 0, (size_t)2 * (max_tokens + 2) * sizeof(long long), c.s));
     HIP_CHECK(hipMemsetAsync(st_ntok, 0, (size_t)b * 4, c.s));
     HIP_CHECK(hipMemsetAsync(st_done, 0, (size_t)b * 4, c.s));
     const int* d_forced = nullptr;
@@ -517,7 +583,13 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
     SpliceParams sp{d_ids, d_row_utt, d_row0, d_rows, c.up(utt_a0), c.up(utt_na), c.up(utt_arow0), R, b, H,
                     qemb ? nullptr : (const bf16_t*)m->embed.w, qemb ? (const uint32_t*)m->embed.w : nullptr, m->embed.scales,
                     m->embed.biases, cfg.group_size, audio_emb, stats, cfg.embed_scale, hid};
-    launch_splice(sp, c.s);
+    if (req->inject_inputs_embeds) {
+        for (int i = 0; i < b; ++i)
+            HIP_CHECK(hipMemcpyAsync(hid + (int64_t)utt_row0[i] * H, req->inject_inputs_embeds + tap_s_off[idx[i]] * H,
+                                     (size_t)utt_rows[i] * H * 4, hipMemcpyHostToDevice, c.s));
+    } else {
+        launch_splice(sp, c.s);
+    }
     if (req->tap_audio_embeds || req->tap_inputs_embeds) {
         for (int i = 0; i < b; ++i) {
             if (req->tap_audio_embeds && ntok[i])
@@ -553,10 +625,12 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             launch_argmax_reduce(p.part_val, p.part_idx, nparts, rows, st_argmax + r0, s);
         }
     };
-    auto step = [&](int advance, int r0, int rows, int* active, hipStream_t s) {
-        StepParams sp2{st_argmax + r0, st_tokens + (size_t)r0 * max_tokens, st_ntok + r0, st_done + r0, st_seen + r0, st_next + r0,
-                       st_len + r0, active, d_forced ? d_forced + (size_t)r0 * max_tokens : nullptr, rows, max_tokens, advance,
-                       req->forced_tokens ? 0 : req->stop_rules};
+    const int rules = req->forced_tokens ? (req->stop_rules == 2 ? 2 : 0) : (req->stop_rules ? 1 : 0);
+    // bookkeeping of one step over `rows` rows that start at row r0 and belong to utterances map[0..rows)
+    auto step = [&](int advance, int r0, int rows, int* active, const int* map, int* map_out, long long* keys_out, hipStream_t s) {
+        StepParams sp2{st_argmax + r0, st_tokens, st_ntok, st_done, st_seen, st_next, st_len, active, d_forced, rows, max_tokens,
+                       advance, rules};
+        sp2.slot = map; sp2.live_out = map_out; sp2.keys_out = keys_out;
         launch_step(sp2, s);
     };
 
@@ -611,7 +685,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         }
         launch_rmsnorm(hid, m->final_norm, x_last, b, H, cfg.rms_eps, d_last, nullptr, 0, 0, c.s);  // :386, last position only
         lm_head(x_last, 0, b, 0, c.s);
-        step(0, 0, b, st_active, c.s);
+        step(0, 0, b, st_active, st_map[0], st_map[1], st_keys + 1, c.s);
         m->arena.restore(mark);
     }
     HIP_CHECK(hipEventRecord(ev.e[3], c.s));
@@ -625,22 +699,54 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         // the co-running kernels stretch each other, which blurs per-kernel timings.
         const char* env_streams = getenv("Q3ASR_DECODE_STREAMS");
         const int n_half = env_streams && atoi(env_streams) >= 2 && b >= 2 ? 2 : 1;
+        // The reference computes nothing for a clip once it has stopped (:571-574).  Here a stopped utterance is skipped by
+        // the attention kernel at once (its done flag) and leaves the step's rows at the next poll: the step kernel
+        // writes the list of utterances still running, and switching the row -> utterance map to that list shrinks
+        // every per-row kernel of the following steps (nothing is moved: the cache and all per-utterance state are
+        // indexed by utterance).  Off for the two-stream mode and for the logits tap (whose host copies are per row).
+        const char* env_retire = getenv("Q3ASR_RETIRE");
+        const bool retire = n_half == 1 && !logits && !(env_retire && atoi(env_retire) == 0);
         // With two streams the attention grid is capped (workgroups loop over their items) so that the
         // other half's projection kernels always find free registers and LDS on every CU.
         const char* env_blocks = getenv("Q3ASR_ATTN_BLOCKS");
         const int attn_blocks = env_blocks ? atoi(env_blocks) : 0;
+        const char* env_gemv = getenv("Q3ASR_DECODE_GEMV");
+        const char* env_auto = getenv("Q3ASR_DECODE_AUTOTUNE");
+        const bool autotune = env_auto && atoi(env_auto) != 0;
         struct Half {
-            int r0, n;
+            int r0, n;      // first row and row count at the start (= utterances of the half)
+            int rows;       // rows still decoded
+            int cur;        // which of st_map holds the half's row -> utterance list
             hipStream_t s;
             float* hid; bf16_t *xn, *qkvb, *qd, *att, *act, *x_last; float* slab;
             int* active_dev;
+            long long* keys;
             q3asr_model::DecodePlan plan;
             bool gemv;  // a handful of rows: projections as fused GEMV kernels (gemv.hip), no partial-sum slabs
         } hv[2];
+        auto gemv_ok = [&](int rows) {
+            return !(env_gemv && atoi(env_gemv) == 0) && gemv_supports(rows, QKV, H, GEMV_NORM_BF16, wf) &&
+                   gemv_supports(rows, H, nh * hd, GEMV_ACC_F32, wf) && gemv_supports(rows, 2 * cfg.inter, H, GEMV_NORM_SWIGLU, wf) &&
+                   gemv_supports(rows, H, cfg.inter, GEMV_ACC_F32, wf);
+        };
+        // Few rows, wide weights: a projection may be split along K so that enough workgroups stream the
+        // weights; the partial sums are reduced by whichever kernel consumes them next.
+        auto set_rows = [&](Half& x, int rows) {
+            x.rows = rows;
+            x.gemv = gemv_ok(rows);
+            x.plan = x.gemv ? q3asr_model::DecodePlan{} : decode_plan(c, rows, wf);
+        };
+        auto slab_need = [&](const q3asr_model::DecodePlan& pl, int rows) {
+            size_t e = (size_t)pl.ks[0] * rows * QKV;
+            e = std::max(e, (size_t)pl.ks[1] * rows * H);
+            e = std::max(e, (size_t)pl.ks[2] * rows * 2 * cfg.inter);
+            return std::max(e, (size_t)pl.ks[3] * rows * H);
+        };
         for (int h = 0; h < n_half; ++h) {
             Half& x = hv[h];
             x.r0 = h ? hv[0].n : 0;
             x.n = n_half == 1 ? b : (h ? b - hv[0].n : (b + 1) / 2);
+            x.cur = 0;
             x.s = h ? m->stream2 : c.s;
             x.hid = c.get<float>((size_t)x.n * H);
             x.xn = c.get<bf16_t>((size_t)x.n * H);
@@ -650,32 +756,33 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             x.act = c.get<bf16_t>((size_t)x.n * cfg.inter);
             x.x_last = x_last + (size_t)x.r0 * H;
             x.active_dev = st_active + h;
-            // Few rows, wide weights: every projection may be split along K so that enough workgroups
-            // stream the weights; the partial sums are reduced by whichever kernel consumes them next.
-            // The (tile, split) pair of each projection is measured once per row count.
-            const char* env_gemv = getenv("Q3ASR_DECODE_GEMV");
-            x.gemv = !(env_gemv && atoi(env_gemv) == 0) && gemv_supports(x.n, QKV, H, GEMV_NORM_BF16, wf) &&
-                     gemv_supports(x.n, H, nh * hd, GEMV_ACC_F32, wf) && gemv_supports(x.n, 2 * cfg.inter, H, GEMV_NORM_SWIGLU, wf) &&
-                     gemv_supports(x.n, H, cfg.inter, GEMV_ACC_F32, wf);
-            x.plan = x.gemv ? q3asr_model::DecodePlan{} : decode_plan(c, x.n, wf);
-            size_t slab_elems = (size_t)x.plan.ks[0] * x.n * QKV;
-            slab_elems = std::max(slab_elems, (size_t)x.plan.ks[1] * x.n * H);
-            slab_elems = std::max(slab_elems, (size_t)x.plan.ks[2] * x.n * 2 * cfg.inter);
-            slab_elems = std::max(slab_elems, (size_t)x.plan.ks[3] * x.n * H);
+            x.keys = st_keys + (size_t)h * (max_tokens + 2);
+            // the slab must hold the partial sums of every plan the half can pass through while it shrinks
+            size_t slab_elems = 256;
+            if (autotune) {
+                slab_elems = (size_t)8 * x.n * std::max(std::max(QKV, 2 * cfg.inter), H);
+            } else {
+                for (int top = 8;; top <<= 1) {
+                    const int r = std::min(top, x.n);
+                    if (!gemv_ok(r)) slab_elems = std::max(slab_elems, slab_need(decode_plan_rule(m, r, wf), r));
+                    if (top >= x.n) break;
+                }
+            }
             x.slab = c.get<float>(slab_elems);
+            set_rows(x, x.n);
         }
         // One projection: split-K partial sums into the slab, or (fused plan) unsplit with the consumer's
         // work in the epilogue, writing `fused_dst` with row stride `fused_ld`.  Returns the number of slabs
         // the consumer still has to reduce (0 when fused).
         auto proj = [&](const Half& x, const bf16_t* A, int64_t lda, const LinearW& W, int which, GemmOut fused_kind, void* fused_dst,
                         int64_t fused_ld) {
-            GemmParams p = gp(c, A, lda, W, x.n);
+            GemmParams p = gp(c, A, lda, W, x.rows);
             if (x.plan.fused[which]) {
                 p.out = fused_dst; p.ldo = fused_ld;
                 launch_gemm(p, A_PLAIN, fused_kind, wf, x.plan.tile[which], x.s);
                 return 0;
             }
-            p.out = x.slab; p.ldo = W.N; p.ksplit = x.plan.ks[which]; p.slab_stride = (int64_t)x.n * W.N;
+            p.out = x.slab; p.ldo = W.N; p.ksplit = x.plan.ks[which]; p.slab_stride = (int64_t)x.rows * W.N;
             launch_gemm(p, A_PLAIN, OUT_SLAB, wf, x.plan.tile[which], x.s);
             return x.plan.ks[which];
         };
@@ -690,6 +797,10 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         int active = b;
         HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
         HIP_CHECK(hipStreamSynchronize(c.s));
+        if (retire && active > 0 && active < b) {   // utterances that stopped on the prefill's token
+            hv[0].cur = 1;
+            set_rows(hv[0], active);
+        }
         if (n_half == 2) {  // the second stream starts after everything queued so far
             HIP_CHECK(hipEventRecord(ev_fork, c.s));
             HIP_CHECK(hipStreamWaitEvent(m->stream2, ev_fork, 0));
@@ -698,11 +809,15 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         int qkv_slabs[2] = {0, 0};  // slabs of the current q/k/v projection (0: bf16 rows in qkvb)
         const char* env_fuse = getenv("Q3ASR_FUSE_ROPE");
         const bool fuse_rope = !(env_fuse && atoi(env_fuse) == 0) && nh / nkv <= 4 && (nh / nkv == 1 || nh / nkv == 2 || nh / nkv == 4);
+        // profiling: the attention's algorithmic bytes are only known on the device (which utterances still run), so its
+        // launches are recorded without work and the exact figure is added after the loop from the step kernel's key counts
+        const bool exact_work = n_half == 1;
+        std::vector<int> attn_launched(max_tokens + 2, 0), attn_timed(max_tokens + 2, 0);
         // enqueues one decode step (every per-step quantity is read from device arrays, so the launches of all
-        // steps are identical; `it` only feeds the profiler's byte count and the logits tap)
+        // steps between two polls are identical; `it` only feeds the profiler's byte count and the logits tap)
         auto issue_step = [&](int it) {
             for (int h = 0; h < n_half; ++h)
-                launch_embed_tokens(st_next + hv[h].r0, hv[h].n, H, qemb ? nullptr : (const bf16_t*)m->embed.w,
+                launch_embed_tokens(st_next, st_map[hv[h].cur] + hv[h].r0, hv[h].rows, H, qemb ? nullptr : (const bf16_t*)m->embed.w,
                                     qemb ? (const uint32_t*)m->embed.w : nullptr, m->embed.scales, m->embed.biases, cfg.group_size,
                                     hv[h].hid, hv[h].s);
             for (int l = 0; l < cfg.layers; ++l) {
@@ -711,23 +826,23 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 bf16_t* vl = vc + l * layer_stride;
                 for (int h = 0; h < n_half; ++h) {
                     const Half& x = hv[h];
+                    const int* map = st_map[x.cur] + x.r0;
                     if (x.gemv) {  // input norm inside the q/k/v kernel
                         GemvParams g;
-                        g.w = L.qkv.w; g.scales = L.qkv.scales; g.biases = L.qkv.biases; g.qgroup = cfg.group_size; g.N = QKV; g.K = H; g.M = x.n; g.hid = x.hid; g.norm_w = L.in_norm; g.eps = cfg.rms_eps;
+                        g.w = L.qkv.w; g.scales = L.qkv.scales; g.biases = L.qkv.biases; g.qgroup = cfg.group_size; g.N = QKV; g.K = H; g.M = x.rows; g.hid = x.hid; g.norm_w = L.in_norm; g.eps = cfg.rms_eps;
                         g.out = x.qkvb; g.ldo = QKV;
                         launch_gemv(g, GEMV_NORM_BF16, x.s);
                         qkv_slabs[h] = 0;
                     } else {
                         // residual += previous layer's down-projection partials (if it left any), then input norm
-                        launch_rmsnorm(x.hid, L.in_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.n * H, x.s);
+                        launch_rmsnorm(x.hid, L.in_norm, x.xn, x.rows, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.rows * H, x.s);
                         qkv_slabs[h] = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
                     }
                     if (!fuse_rope) {
                         const int ns = qkv_slabs[h];
-                        RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.n * QKV, x.qd, (int64_t)nh * hd, x.n,
+                        RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.rows * QKV, x.qd, (int64_t)nh * hd, x.rows,
                                       nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
-                                      m->rope_max_pos, nullptr, nullptr, st_len + x.r0, kl + x.r0 * utt_stride, vl + x.r0 * utt_stride,
-                                      utt_stride, head_stride};
+                                      m->rope_max_pos, map, nullptr, st_len, kl, vl, utt_stride, head_stride};
                         launch_rope(rp, x.s);
                     }
                 }
@@ -738,15 +853,23 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                         const int dep_l = h ? l : (l ? l - 1 : cfg.layers - 1);
                         if (h || l || it > 1) HIP_CHECK(hipStreamWaitEvent(x.s, ev_attn[h ^ 1][dep_l], 0));
                     }
-                    // K and V rows visible this step (counted as if no utterance has stopped yet)
                     double kv_bytes = 0;
-                    for (int i = 0; i < x.n; ++i) kv_bytes += 2.0 * 2.0 * nkv * hd * (double)(utt_rows[x.r0 + i] + it);
-                    DecodeAttnParams dp{x.qd, (int64_t)nh * hd, kl + x.r0 * utt_stride, vl + x.r0 * utt_stride, utt_stride, head_stride,
-                                        st_len + x.r0, fuse_rope ? 0 : 1, x.att, (int64_t)nh * hd, x.n, nkv, nh / nkv, scale};
+                    if (prof_active(x.s)) {
+                        if (exact_work) {
+                            attn_launched[it] += 1;
+                            attn_timed[it] += prof_next_timed("decode_attn_kernel", x.s) ? 1 : 0;
+                        } else {   // K and V rows visible this step, counted as if no utterance had stopped yet
+                            for (int i = 0; i < x.n; ++i) kv_bytes += 2.0 * 2.0 * nkv * hd * (double)(utt_rows[x.r0 + i] + it);
+                        }
+                    }
+                    DecodeAttnParams dp{x.qd, (int64_t)nh * hd, kl, vl, utt_stride, head_stride,
+                                        st_len, fuse_rope ? 0 : 1, x.att, (int64_t)nh * hd, x.rows, nkv, nh / nkv, scale};
                     dp.max_blocks = attn_blocks;
+                    dp.slot = st_map[x.cur] + x.r0;
+                    dp.done = st_done;
                     if (fuse_rope) {  // q/k norm, RoPE and the cache append happen inside the attention kernel
                         const int ns = qkv_slabs[h];
-                        dp.rope = DecodeRopeIn{ns ? nullptr : x.qkvb, ns ? x.slab : nullptr, ns, (int64_t)x.n * QKV, QKV, L.q_norm, L.k_norm,
+                        dp.rope = DecodeRopeIn{ns ? nullptr : x.qkvb, ns ? x.slab : nullptr, ns, (int64_t)x.rows * QKV, QKV, L.q_norm, L.k_norm,
                                                cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos};
                     }
                     launch_decode_attn(dp, hd, x.s, kv_bytes);
@@ -756,7 +879,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                     const Half& x = hv[h];
                     if (x.gemv) {  // o (+= residual), post norm + gate/up + SwiGLU, down (+= residual)
                         GemvParams g;
-                        g.M = x.n; g.eps = cfg.rms_eps; g.qgroup = cfg.group_size;
+                        g.M = x.rows; g.eps = cfg.rms_eps; g.qgroup = cfg.group_size;
                         g.w = L.o.w; g.scales = L.o.scales; g.biases = L.o.biases; g.N = H; g.K = nh * hd; g.a = x.att; g.lda = (int64_t)nh * hd; g.out = x.hid; g.ldo = H;
                         launch_gemv(g, GEMV_ACC_F32, x.s);
                         g.w = L.gate_up.w; g.scales = L.gate_up.scales; g.biases = L.gate_up.biases; g.N = 2 * cfg.inter; g.K = H; g.hid = x.hid; g.norm_w = L.post_norm; g.out = x.act; g.ldo = cfg.inter;
@@ -767,17 +890,18 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                         continue;
                     }
                     const int ns_o = proj(x, x.att, (int64_t)nh * hd, L.o, 1, OUT_F32_ACC, x.hid, H);
-                    launch_rmsnorm(x.hid, L.post_norm, x.xn, x.n, H, cfg.rms_eps, nullptr, x.slab, ns_o, (int64_t)x.n * H, x.s);
+                    launch_rmsnorm(x.hid, L.post_norm, x.xn, x.rows, H, cfg.rms_eps, nullptr, x.slab, ns_o, (int64_t)x.rows * H, x.s);
                     const int ns_gu = proj(x, x.xn, H, L.gate_up, 2, OUT_SWIGLU, x.act, cfg.inter);
-                    if (ns_gu) launch_swiglu_reduce(x.slab, ns_gu, (int64_t)x.n * 2 * cfg.inter, x.n, 2 * cfg.inter, x.act, x.s);
+                    if (ns_gu) launch_swiglu_reduce(x.slab, ns_gu, (int64_t)x.rows * 2 * cfg.inter, x.rows, 2 * cfg.inter, x.act, x.s);
                     pend_down[h] = proj(x, x.act, cfg.inter, L.down, 3, OUT_F32_ACC, x.hid, H);
                 }
             }
             for (int h = 0; h < n_half; ++h) {
                 const Half& x = hv[h];
-                launch_rmsnorm(x.hid, m->final_norm, x.x_last, x.n, H, cfg.rms_eps, nullptr, x.slab, pend_down[h], (int64_t)x.n * H, x.s);
-                lm_head(x.x_last, x.r0, x.n, it, x.s);
-                step(1, x.r0, x.n, x.active_dev, x.s);
+                launch_rmsnorm(x.hid, m->final_norm, x.x_last, x.rows, H, cfg.rms_eps, nullptr, x.slab, pend_down[h], (int64_t)x.rows * H, x.s);
+                lm_head(x.x_last, x.r0, x.rows, it, x.s);
+                step(1, x.r0, x.rows, x.active_dev, st_map[x.cur] + x.r0, st_map[x.cur ^ 1] + x.r0, x.keys + it + 1, x.s);
+                res->decode_rows += x.rows;
             }
         };
         // (Dealing one head's keys to several workgroups with a last-arriver merge was measured at one utterance: no gain,
@@ -792,11 +916,28 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 for (int h = 0; h < n_half; ++h) HIP_CHECK(hipMemcpyAsync(&act_h[h], hv[h].active_dev, 4, hipMemcpyDeviceToHost, hv[h].s));
                 for (int h = 0; h < n_half; ++h) HIP_CHECK(hipStreamSynchronize(hv[h].s));
                 active = act_h[0] + act_h[1];
+                if (retire && active > 0 && active < hv[0].rows) {
+                    // the step just finished wrote the running utterances into the other list: decode those rows from now on
+                    hv[0].cur ^= 1;
+                    set_rows(hv[0], active);
+                }
             }
         }
         if (n_half == 2) {  // everything after the loop runs on the main stream
             HIP_CHECK(hipEventRecord(ev_join, m->stream2));
             HIP_CHECK(hipStreamWaitEvent(c.s, ev_join, 0));
+        }
+        if (prof_active(c.s) && exact_work) {
+            std::vector<long long> keys(max_tokens + 2);
+            HIP_CHECK(hipMemcpyAsync(keys.data(), st_keys, keys.size() * sizeof(long long), hipMemcpyDeviceToHost, c.s));
+            HIP_CHECK(hipStreamSynchronize(c.s));
+            double total = 0, timed = 0;
+            for (int it = 1; it < max_tokens; ++it) {
+                const double bytes = 2.0 * 2.0 * nkv * hd * (double)keys[it];   // K and V rows, bf16, every kv head
+                total += bytes * attn_launched[it];
+                timed += bytes * attn_timed[it];
+            }
+            prof_add_work("decode_attn_kernel", total, timed, c.s);
         }
     }
     HIP_CHECK(hipEventRecord(ev.e[4], c.s));
@@ -832,7 +973,7 @@ void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* re
     const q3asr_config& cfg = m->cfg;
     const int n = req->n_utt;
     res->audio_seconds = res->ms_mel = res->ms_encoder = res->ms_prefill = res->ms_decode = 0;
-    res->decode_steps = res->tokens_total = 0;
+    res->decode_steps = res->tokens_total = res->decode_rows = 0;
     // per-utterance sizes in request order (tap layouts) and the length-sorted processing order
     std::vector<int> frames(n), order(n);
     std::vector<int64_t> tap_a_off(n + 1, 0), tap_s_off(n + 1, 0);
@@ -841,7 +982,7 @@ void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* re
         const int64_t len = req->offsets[u + 1] - req->offsets[u];
         Q3_REQUIRE(len >= 0, "transcribe: offsets must be non-decreasing");
         const int64_t n16 = req->sample_rate == 16000 ? len : (int64_t)((double)len * ratio);
-        Q3_REQUIRE(n16 >= MEL_HOP, "transcribe: an utterance is shorter than one 10 ms frame");
+        if (n16 < MEL_HOP) throw Q3Error("q3asr: transcribe: utterance " + std::to_string(u) + " is shorter than one 10 ms frame");
         frames[u] = mel_frames_out(n16);
         const int na = model_output_length(cfg, frames[u]);
         int nl = 0;

@@ -23,6 +23,7 @@ class Q3Request(ctypes.Structure):
         ("forced_tokens", ctypes.POINTER(ctypes.c_int32)),
         ("tap_logits", ctypes.POINTER(ctypes.c_float)), ("tap_steps", ctypes.c_int),
         ("tap_audio_embeds", ctypes.POINTER(ctypes.c_float)), ("tap_inputs_embeds", ctypes.POINTER(ctypes.c_float)),
+        ("inject_inputs_embeds", ctypes.POINTER(ctypes.c_float)),
     ]
 
 
@@ -33,7 +34,7 @@ class Q3Result(ctypes.Structure):
         ("audio_seconds", ctypes.c_double),
         ("ms_mel", ctypes.c_double), ("ms_encoder", ctypes.c_double), ("ms_prefill", ctypes.c_double),
         ("ms_decode", ctypes.c_double),
-        ("decode_steps", ctypes.c_int64), ("tokens_total", ctypes.c_int64),
+        ("decode_steps", ctypes.c_int64), ("tokens_total", ctypes.c_int64), ("decode_rows", ctypes.c_int64),
     ]
 
 
@@ -41,7 +42,7 @@ EXPORTS = [
     "q3asr_last_error", "q3asr_create", "q3asr_destroy", "q3asr_load_tensor", "q3asr_finalize", "q3asr_mel_filterbank",
     "q3asr_mel", "q3asr_encode", "q3asr_output_length", "q3asr_transcribe_tokens", "q3asr_op_gemm", "q3asr_op_gemm_q4",
     "q3asr_op_attention", "q3asr_profile_start", "q3asr_profile_stop", "q3asr_op_gemm_time", "q3asr_op_greedy_rules",
-    "q3asr_op_read_bandwidth", "q3asr_op_mfma_f32_rate",
+    "q3asr_op_read_bandwidth", "q3asr_op_mfma_f32_rate", "q3asr_workspace_bytes",
 ]
 
 
@@ -62,6 +63,8 @@ def load():
     lib.q3asr_encode.argtypes = [c_void_p, c_void_p, c_int, P(ctypes.c_int32), c_int, c_int, c_void_p, ctypes.c_int64,
                                  P(ctypes.c_int32), c_int]
     lib.q3asr_output_length.argtypes = [c_void_p, c_int]
+    lib.q3asr_workspace_bytes.argtypes = [c_void_p]
+    lib.q3asr_workspace_bytes.restype = ctypes.c_int64
     lib.q3asr_transcribe_tokens.argtypes = [c_void_p, P(Q3Request), P(Q3Result)]
     lib.q3asr_op_gemm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.q3asr_op_gemm_q4.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]

@@ -32,7 +32,48 @@ class TranscribeOutput:
     ms: dict                           # device time per stage
     decode_steps: int
     tokens_total: int
+    decode_rows: int = 0               # sum over the decode steps of the rows computed
     taps: dict = field(default_factory=dict)
+
+
+def config_from_json(cj):
+    """(preset, overrides) for make_config from a checkpoint's config.json, reading what the reference's
+    loadTextConfigIfPresent reads (Qwen3ASR.swift:774-818) plus the audio_config the 1.7B model needs."""
+    tc = cj.get("thinker_config", cj).get("text_config", {})
+    quant = cj.get("quantization") or cj.get("quantization_config")
+    # encoder shape when the checkpoint names none: the true 1.7B shape beside a 2048-wide decoder, else the
+    # reference's only one (0.6B)
+    preset = "1.7b" if tc.get("hidden_size", 1024) == 2048 else "0.6b"
+    kw = dict(weight_format=1 if quant else 0)
+    for src, dst in (("hidden_size", "hidden"), ("num_hidden_layers", "layers"), ("num_attention_heads", "heads"),
+                     ("num_key_value_heads", "kv_heads"), ("head_dim", "head_dim"), ("intermediate_size", "inter"),
+                     ("vocab_size", "vocab"), ("rms_norm_eps", "rms_eps"), ("rope_theta", "rope_theta")):
+        if src in tc:
+            kw[dst] = tc[src]
+    # rope_scaling.interleaved / mrope_section and quantization.group_size / bits: Qwen3ASR.swift:806-815;
+    # rotaryDim = 2 * sum(mrope_section) clamped to the head (Configuration.swift:75-80)
+    rs = tc.get("rope_scaling") or {}
+    if isinstance(rs.get("interleaved"), bool):
+        kw["rope_interleaved"] = int(rs["interleaved"])
+    if isinstance(rs.get("mrope_section"), list):
+        head_dim = kw.get("head_dim", 128)
+        rot = min(head_dim, 2 * max(0, min(int(sum(rs["mrope_section"])), head_dim // 2)))
+        if rot == 0:
+            raise ValueError("config.json: an empty mrope_section (no rotary embedding at all) is not supported")
+        kw["rotary_dim"] = rot
+    if isinstance(quant, dict):
+        for src, dst in (("group_size", "group_size"), ("bits", "bits")):
+            if isinstance(quant.get(src), int):
+                kw[dst] = quant[src]
+    # The reference keeps its built-in encoder shape (AudioEncoder.swift:26-43); a checkpoint's own audio_config,
+    # when present (HF layout: thinker_config.audio_config), is what the 1.7B model needs.
+    ac = cj.get("thinker_config", cj).get("audio_config", {})
+    for src, dst in (("d_model", "enc_d_model"), ("encoder_layers", "enc_layers"), ("encoder_attention_heads", "enc_heads"),
+                     ("encoder_ffn_dim", "enc_ffn"), ("output_dim", "enc_out_dim"), ("downsample_hidden_size", "conv_channels"),
+                     ("num_mel_bins", "n_mels"), ("n_window", "n_window"), ("n_window_infer", "n_window_infer")):
+        if src in ac:
+            kw[dst] = ac[src]
+    return preset, kw
 
 
 class WhisperFeatureExtractor:
@@ -156,23 +197,7 @@ class Qwen3ASRModel:
         from .safetensors_io import load_dir
         with open(os.path.join(model_dir, "config.json")) as f:
             cj = json.load(f)
-        tc = cj.get("thinker_config", cj).get("text_config", {})
-        quant = cj.get("quantization") or cj.get("quantization_config")
-        preset = "1.7b" if tc.get("hidden_size", 1024) >= 2048 else "0.6b"
-        kw = dict(weight_format=1 if quant else 0)
-        for src, dst in (("hidden_size", "hidden"), ("num_hidden_layers", "layers"), ("num_attention_heads", "heads"),
-                         ("num_key_value_heads", "kv_heads"), ("head_dim", "head_dim"), ("intermediate_size", "inter"),
-                         ("vocab_size", "vocab"), ("rms_norm_eps", "rms_eps"), ("rope_theta", "rope_theta")):
-            if src in tc:
-                kw[dst] = tc[src]
-        # The reference keeps its built-in encoder shape (AudioEncoder.swift:26-43); a checkpoint's own audio_config,
-        # when present (HF layout: thinker_config.audio_config), is what the 1.7B model needs.
-        ac = cj.get("thinker_config", cj).get("audio_config", {})
-        for src, dst in (("d_model", "enc_d_model"), ("encoder_layers", "enc_layers"), ("encoder_attention_heads", "enc_heads"),
-                         ("encoder_ffn_dim", "enc_ffn"), ("output_dim", "enc_out_dim"), ("downsample_hidden_size", "conv_channels"),
-                         ("num_mel_bins", "n_mels"), ("n_window", "n_window"), ("n_window_infer", "n_window_infer")):
-            if src in ac:
-                kw[dst] = ac[src]
+        preset, kw = config_from_json(cj)
         kw.update(overrides)
         m = cls(make_config(preset, **kw), device)
         m.load_checkpoint(load_dir(model_dir))
@@ -218,7 +243,7 @@ class Qwen3ASRModel:
         return joined, per_utt
 
     def transcribe_batch(self, audios, sample_rate=16000, max_tokens=448, lang_ids=None, stop_rules=True, forced_tokens=None,
-                         tap_steps=0, tap_embeds=False, device_audio=None):
+                         tap_steps=0, tap_embeds=False, device_audio=None, inject_inputs_embeds=None):
         """audios: list of fp32 arrays (host).  device_audio: (device pointer, offsets int64[n+1]) of samples
         already resident in HBM, used instead of `audios`."""
         if device_audio is not None:
@@ -236,7 +261,8 @@ class Qwen3ASRModel:
         req = _lib.Q3Request()
         req.audio, req.offsets, req.n_utt = ptr, _ptr(off, ctypes.c_int64), n
         req.sample_rate, req.audio_space = int(sample_rate), space
-        req.max_tokens, req.stop_rules = int(max_tokens), 1 if stop_rules else 0
+        # stop_rules: True / False, or "forced" = the reference's rules evaluated on the teacher-forced inputs (scripted stops)
+        req.max_tokens, req.stop_rules = int(max_tokens), 2 if stop_rules == "forced" else (1 if stop_rules else 0)
         holders = [off, keep]
         if lang_ids is not None:
             lo = np.zeros(n + 1, dtype=np.int32)
@@ -248,6 +274,10 @@ class Qwen3ASRModel:
             ft = np.ascontiguousarray(forced_tokens, dtype=np.int32).reshape(n, max_tokens)
             req.forced_tokens = _ptr(ft, ctypes.c_int32)
             holders.append(ft)
+        if inject_inputs_embeds is not None:      # packed [sum S_u][hidden] rows that replace the spliced prompt embeddings
+            inj = np.ascontiguousarray(inject_inputs_embeds, dtype=np.float32)
+            req.inject_inputs_embeds = _ptr(inj, ctypes.c_float)
+            holders.append(inj)
         taps = {}
         if tap_steps:
             taps["logits"] = np.zeros((n, tap_steps, self.cfg.vocab), dtype=np.float32)
@@ -268,7 +298,11 @@ class Qwen3ASRModel:
         return TranscribeOutput(
             tokens=[tokens[i, :ntok[i]].tolist() for i in range(n)], n_audio_tokens=naud, audio_seconds=res.audio_seconds,
             ms=dict(mel=res.ms_mel, encoder=res.ms_encoder, prefill=res.ms_prefill, decode=res.ms_decode),
-            decode_steps=int(res.decode_steps), tokens_total=int(res.tokens_total), taps=taps)
+            decode_steps=int(res.decode_steps), tokens_total=int(res.tokens_total), decode_rows=int(res.decode_rows), taps=taps)
+
+    def workspace_bytes(self):
+        """Device memory the per-call workspace holds at the moment."""
+        return int(self._lib.q3asr_workspace_bytes(self._h))
 
     # ---- per-kernel timing ----
     def profile_start(self, stride=1):

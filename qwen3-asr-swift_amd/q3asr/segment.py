@@ -12,6 +12,7 @@ import numpy as np
 MAX_SECONDS = 30.0          # WhisperFeatureExtractor.chunk_length (AudioPreprocessing.swift:13)
 FRAME_MS = 20
 ENERGY_THRESHOLD = 0.01     # SimpleVAD.Config.energyThreshold (TranscriptStabilizer.swift:159)
+MIN_PIECE_MS = 100          # no piece shorter than this: the library rejects utterances below one 10 ms frame
 
 
 def frame_rms(audio, frame):
@@ -43,6 +44,13 @@ def split_points(audio, sample_rate, max_seconds=MAX_SECONDS, search_seconds=5.0
         out.append((start, cut))
         start = cut
     out.append((start, n))
+    # A recording a few ms over a multiple of the window leaves a sliver: move the last cut back so that the tail
+    # piece reaches the minimum length (nothing is dropped, no piece grows past the window).
+    min_len = max(1, sample_rate * MIN_PIECE_MS // 1000)
+    if len(out) >= 2 and out[-1][1] - out[-1][0] < min_len:
+        s0, _ = out[-2]
+        cut = max(s0 + 1, n - min_len)
+        out[-2], out[-1] = (s0, cut), (cut, n)
     return out
 
 

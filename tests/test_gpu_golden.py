@@ -1,0 +1,118 @@
+"""The HIP path against the committed golden vectors directly (no CPU restatement in between).
+
+The goldens come from independent implementations of the shared architecture (tests/golden/make_golden.py: the
+float64 Whisper feature extractor, the Qwen3-ASR audio encoder + projector and the Qwen3 decoder of `transformers`),
+because the reference's own tests hold no numerical vector for this path and it cannot run here: parity is pinned to
+those implementations at the bounds below, not to the Swift/MLX build."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, read_wav_pcm16
+from q3asr import Qwen3ASRModel, make_config, synth
+
+pytestmark = pytest.mark.gpu
+
+# Log-mel against the float64 extractor, with the library's own fp32 slaney table (nothing injected).  Measured on
+# MI355X: 1.02e-4 ... 1.11e-4 on the three slices; the excess over 1e-4 sits in isolated bins fed by the table's
+# smallest edge weight (1.2e-4 in filter 53, which moves by 0.2 % between an fp32 and a float64 evaluation of the
+# slaney formula, AudioPreprocessing.swift:23-126).
+MEL_HF_TOL = 1.2e-4
+# bf16 activations between GEMMs on the GPU against fp32 torch
+ENC_RTOL = 3e-2
+LOGIT_RTOL = 4e-2
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-9)
+
+
+def test_mel_of_the_reference_clip_matches_hf_float64(tiny_model):
+    """q3asr_mel on the reference's own 24 kHz test clip (resampled on the GPU, AudioPreprocessing.swift:347-365)
+    against the float64 extractor's slices: onset, loudest second, digital silence."""
+    m = tiny_model[0]
+    audio, rate = read_wav_pcm16(os.path.join(GOLDEN, "test_audio.wav"))
+    got = m.feature_extractor.process(audio, rate)
+    assert got.shape == (128, 2000)
+    worst = 0.0
+    for name, sl in (("g1_mel_hf_f450_600.npy", slice(450, 600)), ("g1_mel_hf_f700_800.npy", slice(700, 800)),
+                     ("g1_mel_hf_f1900_2000.npy", slice(1900, 2000))):
+        ref = np.load(os.path.join(GOLDEN, name))
+        err = float(np.abs(got[:, sl] - ref).max())
+        worst = max(worst, err)
+        print(f"mel vs HF float64 {name}: max abs err {err:.3e}, share of bins above 1e-4: {(np.abs(got[:, sl] - ref) > 1e-4).mean():.2e}")
+    assert worst <= MEL_HF_TOL
+    fb = m.feature_extractor.mel_filterbank()
+    assert np.abs(fb - np.load(os.path.join(GOLDEN, "g2_filterbank_hf.npy"))).max() <= 5e-7
+
+
+def test_mel_residual_against_the_reference_literal_twiddles(tiny_model):
+    """The Swift evaluates the DFT angle -2*pi*k*n/400 in fp32 (AudioPreprocessing.swift:170-176); the kernel uses
+    exact twiddles (what the float64 extractor computes).  The distance between the GPU output and a literal
+    restatement of the Swift arithmetic is recorded here with a measured bound: it is the twiddle rounding noise
+    (k*n up to 80 000 loses ~1e-4 relative in the angle), concentrated near the max-8 dB clamp floor."""
+    m = tiny_model[0]
+    audio, rate = read_wav_pcm16(os.path.join(GOLDEN, "test_audio.wav"))
+    a16 = oracle.mel.resample_linear(audio, rate, 16000)[80000:128000]      # 5 - 8 s: the spoken part
+    got = m.feature_extractor.process(a16, 16000)
+    literal = oracle.mel.extract_features(a16, "literal")
+    exact = oracle.mel.extract_features(a16, "exact")
+    d_lit, d_exact = np.abs(got - literal), np.abs(got - exact)
+    print(f"GPU vs literal-twiddle restatement: max {d_lit.max():.3e}, mean {d_lit.mean():.3e}, share above 1e-4 {(d_lit > 1e-4).mean():.3e}; "
+          f"GPU vs exact-twiddle restatement: max {d_exact.max():.3e}")
+    assert d_lit.max() <= 1.5e-3          # measured 7e-4: the literal form's own noise, absent from the exact form
+    assert (d_lit > 1e-4).mean() <= 2e-2  # confined to a small share of the bins
+    assert d_lit.mean() <= 2e-5
+    assert d_exact.max() <= 2.5e-4
+
+
+@pytest.fixture(scope="module")
+def g3_model():
+    cfg = make_config("tiny")
+    m = Qwen3ASRModel.from_checkpoint(cfg, synth.make_checkpoint(cfg, seed=11))
+    yield m, cfg
+    m.close()
+
+
+@pytest.mark.parametrize("frames", [250, 300, 1000])
+def test_encoder_matches_hf_torch(g3_model, frames):
+    """q3asr_encode on the golden log-mel input against the transformers encoder + projector output."""
+    m, cfg = g3_model
+    g = np.load(os.path.join(GOLDEN, f"g3_encoder_hf_{frames}.npz"))
+    got = m.audio_encoder(g["mel"])
+    assert got.shape == g["out"].shape
+    err = _rel(got, g["out"])
+    print(f"encoder {frames} frames vs HF fp32: rel err {err:.3e}")
+    assert err <= ENC_RTOL
+
+
+def test_decoder_matches_hf_torch_rotate_half():
+    """Prefill + 8 greedy steps of the decoder on the golden inputsEmbeds (rotate-half RoPE, no embedding rescale:
+    the upstream Qwen3 form, QuantizedTextDecoder.swift:253-259 is the same branch) against transformers' Qwen3Model:
+    per-step logits within the bf16 tolerance and the same ids wherever the golden top-2 margin exceeds it."""
+    cfg = make_config("tiny", vocab=512, rope_interleaved=0, embed_scale=0)
+    g = np.load(os.path.join(GOLDEN, "g4_decoder_hf.npz"))
+    x, ref_logits, ref_ids = g["x"], g["logits"], g["ids"].tolist()
+    assert x.shape == (37, cfg.hidden) and ref_logits.shape == (9, 512)
+    m = Qwen3ASRModel.from_checkpoint(cfg, synth.make_checkpoint(cfg, seed=13))
+    try:
+        # a 1.7 s clip gives 22 audio tokens, i.e. a 37-row prompt whose embeddings are replaced by the golden rows
+        audio = synth.synth_audio(170 * 160, 1)
+        assert m.audio_encoder.output_length(170) == 22
+        forced = np.asarray([ref_ids], dtype=np.int32)
+        out = m.transcribe_batch([audio], 16000, max_tokens=9, stop_rules=False, forced_tokens=forced, tap_steps=9,
+                                 inject_inputs_embeds=x)
+        got = out.taps["logits"][0]
+        err = _rel(got, ref_logits)
+        print(f"decoder vs HF fp32: logits rel err {err:.3e}")
+        assert err <= LOGIT_RTOL
+        for i in range(9):
+            srt = np.sort(ref_logits[i])
+            if srt[-1] - srt[-2] > 2 * LOGIT_RTOL * np.abs(ref_logits[i]).max():
+                assert out.tokens[0][i] == ref_ids[i], i
+        free = m.transcribe_batch([audio], 16000, max_tokens=9, stop_rules=False, inject_inputs_embeds=x)
+        assert free.tokens[0][0] == out.tokens[0][0]
+    finally:
+        m.close()

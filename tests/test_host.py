@@ -228,3 +228,63 @@ def test_sharded_transcribe_gathers_over_gloo():
         assert 0 < len(s) < 9
         assert n_tok == sum(len(t) for t in want)
         assert abs(audio_s - sum(1 + (i * 7) % 11 for i in range(9))) < 1e-9
+
+
+def test_bench_launcher_starts_one_rank_per_gpu(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N ranks itself: every child gets its own RANK / LOCAL_RANK,
+    the shared WORLD_SIZE / MASTER_ADDR / MASTER_PORT and the original arguments; rank 0's output is passed through
+    and a failing rank fails the run."""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    envs = bench.rank_envs(4, 29517, base_env={"PATH": "/bin"})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29517" for e in envs)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/bin" for e in envs)
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import json, os, sys\n"
+        "keys = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')\n"
+        "open(os.path.join(os.path.dirname(__file__), 'rank%s.json' % os.environ['RANK']), 'w').write(\n"
+        "    json.dumps({'env': {k: os.environ[k] for k in keys}, 'argv': sys.argv[1:]}))\n"
+        "print(json.dumps({'n_gpus': int(os.environ['WORLD_SIZE'])}))\n"
+        "sys.exit(3 if '--fail' in sys.argv and os.environ['RANK'] == '1' else 0)\n")
+    driver = ("import sys; sys.path.insert(0, %r); import bench; bench.spawn_ranks(2, %%r, child=[sys.executable, %r])" % (root, str(child)))
+    run = subprocess.run([sys.executable, "-c", driver % (["--gpus", "2", "--steps", "1"],)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert json.loads(run.stdout.strip().splitlines()[-1]) == {"n_gpus": 2}            # exactly rank 0's line
+    seen = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(2)]
+    assert [s["env"]["RANK"] for s in seen] == ["0", "1"] and all(s["env"]["WORLD_SIZE"] == "2" for s in seen)
+    assert seen[0]["env"]["MASTER_PORT"] == seen[1]["env"]["MASTER_PORT"] and seen[0]["env"]["MASTER_ADDR"] == "127.0.0.1"
+    assert all(s["argv"] == ["--gpus", "2", "--steps", "1"] for s in seen)
+    run = subprocess.run([sys.executable, "-c", driver % (["--fail"],)], capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0 and "ranks failed" in run.stderr
+
+
+def test_config_json_fields_the_reference_reads():
+    """loadTextConfigIfPresent (Qwen3ASR.swift:774-818): rope_scaling.interleaved and mrope_section
+    (rotaryDim = 2 * sum, clamped to the head, Configuration.swift:75-80) and quantization.group_size / bits."""
+    from q3asr.model import config_from_json
+    preset, kw = config_from_json({"thinker_config": {"text_config": {
+        "hidden_size": 2048, "head_dim": 128, "rope_theta": 1000000, "rope_scaling": {"interleaved": False, "mrope_section": [8, 12, 12]}}},
+        "quantization": {"group_size": 64, "bits": 4}})
+    assert preset == "1.7b" and kw["rope_interleaved"] == 0 and kw["rotary_dim"] == 64
+    assert kw["weight_format"] == 1 and kw["group_size"] == 64 and kw["bits"] == 4
+    preset, kw = config_from_json({"thinker_config": {"text_config": {"hidden_size": 1024, "rope_scaling": {"interleaved": True, "mrope_section": [24, 20, 20]}}}})
+    assert preset == "0.6b" and kw["rope_interleaved"] == 1 and kw["rotary_dim"] == 128 and kw["weight_format"] == 0
+    preset, kw = config_from_json({"thinker_config": {"text_config": {}}})
+    assert "rope_interleaved" not in kw and "rotary_dim" not in kw        # defaults: interleaved, full rotary
+    with pytest.raises(ValueError):
+        config_from_json({"thinker_config": {"text_config": {"rope_scaling": {"mrope_section": []}}}})
+    # a tail piece shorter than 100 ms is folded into the previous cut instead of becoming an utterance of its own
+    from q3asr.segment import split_points
+    n = 16000 * 60 + 37
+    spans = split_points(np.zeros(n, np.float32), 16000, energy=False)
+    assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert all(1600 <= e - s <= 480000 for s, e in spans)
+    assert len(split_points(np.zeros(480000, np.float32), 16000)) == 1
