@@ -7,6 +7,7 @@
 #include "ops.h"
 #include "mel.h"
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -151,7 +152,8 @@ struct q3asr_model {
         int tile[4], ks[4];  // qkv, o, gate_up, down
         int fused[4];        // 1: unsplit, with the consumer's work in the GEMM epilogue instead of partial-sum slabs
     };
-    std::map<int, DecodePlan> decode_plans;
+    std::map<int, DecodePlan> decode_plans;   // measured plans (tuning runs), per row bucket
+    std::set<int> plans_reported;             // buckets whose plan the verbose log has shown
     hipStream_t stream2 = nullptr;           // second decode stream (the two halves of a large group)
     std::vector<hipEvent_t> chain_events;    // ordering events between the two decode streams
 

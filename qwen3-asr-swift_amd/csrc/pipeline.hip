@@ -7,6 +7,7 @@
 #include "model.h"
 #include "gemv.h"
 #include "prof.h"
+#include "decode_plan_table.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -331,7 +332,8 @@ namespace {
 // The decode-step projections run `rows` rows against wide weights, where the best (tile, split-K) pair depends
 // on the row count and on the projection's shape.  The plan is a fixed function of (rows, N, K, weight format),
 // evaluated per power-of-two bucket of the row count, so that equal requests are computed by equal kernels in
-// every process and on every rank (the reference is deterministic for a given input).  All unsplit variants
+// every process and on every rank (the reference is deterministic for a given input): a table of the fastest
+// measured variant for the known model shapes (decode_plan_table.h), a workgroup-count rule for any other shape.  All unsplit variants
 // accumulate K in the same order with the same MFMA, so the tile never changes a result; the split count and the
 // fused-versus-slab form do (within the bf16 tolerance).  Q3ASR_DECODE_TILE / _SPLIT / _NO_FUSE pin one variant;
 // Q3ASR_DECODE_AUTOTUNE=1 replaces the rule by a measurement of every candidate on layer 0's weights (tuning runs).
@@ -373,9 +375,17 @@ q3asr_model::DecodePlan decode_plan_rule(const q3asr_model* m, int rows, GemmWFm
             const int64_t wgs = (int64_t)cdiv(R, bm) * cdiv(N, bn);
             while (ks < 8 && wgs * ks < 256 && ktiles / (ks * 2) >= 4) ks *= 2;
         }
+        bool want_fused = ks == 1;
+        for (const DecodePlanEntry& e : DECODE_PLAN_TABLE)
+            if (e.N == N && e.K == K && e.wfmt == (int)wf && e.bucket == R) {
+                tile = e.tile;
+                ks = std::max(1, e.split);
+                want_fused = e.split == 0;
+                break;
+            }
         if (env_tile) tile = atoi(env_tile);
-        if (env_split) ks = std::max(1, atoi(env_split));   // "0" asks for the fused form, "1" for one slab
-        const bool fused = ks == 1 && allow_fused && !(env_split && atoi(env_split) != 0);
+        if (env_split) { ks = std::max(1, atoi(env_split)); want_fused = atoi(env_split) == 0; }   // "0": fused form, "1": one slab
+        const bool fused = want_fused && ks == 1 && allow_fused;
         if (tile == 1 && g == 2 && fused) tile = 2;
         plan.tile[g] = tile;
         plan.ks[g] = ks;
@@ -384,15 +394,21 @@ q3asr_model::DecodePlan decode_plan_rule(const q3asr_model* m, int rows, GemmWFm
     return plan;
 }
 
+// Times every candidate of the four projections at `b` rows.  Launch i of a candidate uses layer i's weights, so the
+// weights come from HBM as they do in a decode step (28 layers of the 1.7B model are 3.4 GB, far beyond the caches),
+// while the activations stay hot as the previous kernel's output would be.
 q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
     q3asr_model* m = c.m;
-    const DecLayerW& L = m->dec[0];
-    const LinearW* W[4] = {&L.qkv, &L.o, &L.gate_up, &L.down};
+    const int layers = (int)m->dec.size();
+    auto weight = [&](int l, int g) -> const LinearW& {
+        const DecLayerW& L = m->dec[l];
+        return g == 0 ? L.qkv : g == 1 ? L.o : g == 2 ? L.gate_up : L.down;
+    };
     q3asr_model::DecodePlan plan;
     const char* env_tile = getenv("Q3ASR_DECODE_TILE");
     const char* env_split = getenv("Q3ASR_DECODE_SPLIT");
     int max_n = 0, max_k = 0;
-    for (auto* w : W) { max_n = std::max(max_n, w->N); max_k = std::max(max_k, w->K); }
+    for (int g = 0; g < 4; ++g) { max_n = std::max(max_n, weight(0, g).N); max_k = std::max(max_k, weight(0, g).K); }
     const auto mark = m->arena.mark();
     bf16_t* A = c.get<bf16_t>((size_t)b * max_k);
     float* slab = c.get<float>((size_t)8 * b * max_n);
@@ -400,11 +416,11 @@ q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
-    constexpr int REPS = 8;
     // epilogue of the unsplit, fused form of each projection: bf16 q/k/v rows, residual add, SwiGLU, residual add
     const GemmOut fused_out[4] = {OUT_BF16, OUT_F32_ACC, OUT_SWIGLU, OUT_F32_ACC};
     const bool allow_fused = !getenv("Q3ASR_DECODE_NO_FUSE");
     for (int g = 0; g < 4; ++g) {
+        const int N = weight(0, g).N, K = weight(0, g).K;
         plan.tile[g] = b > 64 ? 2 : 1;
         plan.ks[g] = 1;
         plan.fused[g] = 0;
@@ -413,26 +429,33 @@ q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
             if ((tile == 3 && (wf != W_BF16 || b <= 128)) || (tile == 1 && b > 512)) continue;
             if (env_tile && atoi(env_tile) != tile) continue;
             for (int ks : {0, 1, 2, 4, 8}) {  // 0: the fused form
-                if (ks > 1 && ks * 4 > W[g]->K / 64) continue;  // at least four K tiles per split
+                if (ks > 1 && ks * 4 > K / 64) continue;  // at least four K tiles per split
                 if (env_split && atoi(env_split) != ks) continue;
                 if (ks == 0 && (!allow_fused || (g == 2 && tile == 1))) continue;  // no SwiGLU epilogue on the 64x64 tile
-                GemmParams p = gp(c, A, W[g]->K, *W[g], b);
-                p.out = slab; p.ldo = g == 2 && ks == 0 ? W[g]->N / 2 : W[g]->N;
-                p.ksplit = std::max(ks, 1); p.slab_stride = (int64_t)b * W[g]->N;
                 const GemmOut out = ks == 0 ? fused_out[g] : OUT_SLAB;
-                for (int i = 0; i < 2; ++i) launch_gemm(p, A_PLAIN, out, wf, tile, c.s);
-                HIP_CHECK(hipEventRecord(e0, c.s));
-                for (int i = 0; i < REPS; ++i) launch_gemm(p, A_PLAIN, out, wf, tile, c.s);
-                HIP_CHECK(hipEventRecord(e1, c.s));
-                HIP_CHECK(hipEventSynchronize(e1));
-                float ms = 0;
-                HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                float ms = 1e30f;
+                for (int pass = 0; pass < 3; ++pass) {   // pass 0 warms up; the faster of the other two counts
+                    if (pass) HIP_CHECK(hipEventRecord(e0, c.s));
+                    for (int l = 0; l < layers; ++l) {
+                        GemmParams p = gp(c, A, K, weight(l, g), b);
+                        p.out = slab; p.ldo = g == 2 && ks == 0 ? N / 2 : N;
+                        p.ksplit = std::max(ks, 1); p.slab_stride = (int64_t)b * N;
+                        launch_gemm(p, A_PLAIN, out, wf, tile, c.s);
+                    }
+                    if (pass) {
+                        HIP_CHECK(hipEventRecord(e1, c.s));
+                        HIP_CHECK(hipEventSynchronize(e1));
+                        float t = 0;
+                        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+                        ms = std::min(ms, t);
+                    }
+                }
                 // a split's consumer reads the slabs back (~3 TB/s); gate/up partials also need the reduce kernel
-                const double extra_us = ks == 0 ? 0.0 : ks * b * (double)W[g]->N * 4.0 / 3.0e6 + (g == 2 ? 4.0 : 0.0);
-                const double us = ms * 1000.0 / REPS + extra_us;
+                const double extra_us = ks == 0 ? 0.0 : ks * b * (double)N * 4.0 / 3.0e6 + (g == 2 ? 4.0 : 0.0);
+                const double us = ms * 1000.0 / layers + extra_us;
                 if (getenv("Q3ASR_VERBOSE") && atoi(getenv("Q3ASR_VERBOSE")) > 1)
                     fprintf(stderr, "q3asr: rows %d proj %d tile %d split %d: %.1f us (+%.1f us for its partial sums)\n", b, g, tile, ks,
-                            ms * 1000.0 / REPS, extra_us);
+                            ms * 1000.0 / layers, extra_us);
                 if (us < best) { best = us; plan.tile[g] = tile; plan.ks[g] = std::max(ks, 1); plan.fused[g] = ks == 0; }
             }
         }
@@ -446,16 +469,23 @@ q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
 q3asr_model::DecodePlan decode_plan(Ctx& c, int rows, GemmWFmt wf) {
     q3asr_model* m = c.m;
     const int bucket = plan_bucket(rows);
-    const auto hit = m->decode_plans.find(bucket);
-    if (hit != m->decode_plans.end()) return hit->second;
     const char* env_auto = getenv("Q3ASR_DECODE_AUTOTUNE");
     const bool measured = env_auto && atoi(env_auto) != 0;
-    const q3asr_model::DecodePlan plan = measured ? decode_plan_measured(c, rows, wf) : decode_plan_rule(m, rows, wf);
-    if (getenv("Q3ASR_VERBOSE"))
+    q3asr_model::DecodePlan plan;
+    bool fresh = true;
+    if (measured) {   // a measurement is kept per bucket; the rule is cheap and follows the pinning variables of each call
+        const auto hit = m->decode_plans.find(bucket);
+        fresh = hit == m->decode_plans.end();
+        plan = fresh ? decode_plan_measured(c, rows, wf) : hit->second;
+        m->decode_plans[bucket] = plan;
+    } else {
+        plan = decode_plan_rule(m, rows, wf);
+        fresh = m->plans_reported.insert(bucket).second;
+    }
+    if (fresh && getenv("Q3ASR_VERBOSE"))
         fprintf(stderr, "q3asr: decode plan for up to %d rows%s (tile/split, split 0 = fused epilogue): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n",
                 bucket, measured ? " (measured)" : "", plan.tile[0], plan.fused[0] ? 0 : plan.ks[0], plan.tile[1], plan.fused[1] ? 0 : plan.ks[1],
                 plan.tile[2], plan.fused[2] ? 0 : plan.ks[2], plan.tile[3], plan.fused[3] ? 0 : plan.ks[3]);
-    m->decode_plans[bucket] = plan;
     return plan;
 }
 
@@ -705,7 +735,8 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         // every per-row kernel of the following steps (nothing is moved: the cache and all per-utterance state are
         // indexed by utterance).  Off for the two-stream mode and for the logits tap (whose host copies are per row).
         const char* env_retire = getenv("Q3ASR_RETIRE");
-        const bool retire = n_half == 1 && !logits && !(env_retire && atoi(env_retire) == 0);
+        const bool skip_done = !(env_retire && atoi(env_retire) == 0);   // Q3ASR_RETIRE=0: every row is computed until the group ends
+        const bool retire = n_half == 1 && !logits && skip_done;
         // With two streams the attention grid is capped (workgroups loop over their items) so that the
         // other half's projection kernels always find free registers and LDS on every CU.
         const char* env_blocks = getenv("Q3ASR_ATTN_BLOCKS");
@@ -866,7 +897,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                                         st_len, fuse_rope ? 0 : 1, x.att, (int64_t)nh * hd, x.rows, nkv, nh / nkv, scale};
                     dp.max_blocks = attn_blocks;
                     dp.slot = st_map[x.cur] + x.r0;
-                    dp.done = st_done;
+                    dp.done = skip_done ? st_done : nullptr;
                     if (fuse_rope) {  // q/k norm, RoPE and the cache append happen inside the attention kernel
                         const int ns = qkv_slabs[h];
                         dp.rope = DecodeRopeIn{ns ? nullptr : x.qkvb, ns ? x.slab : nullptr, ns, (int64_t)x.rows * QKV, QKV, L.q_norm, L.k_norm,

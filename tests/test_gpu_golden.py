@@ -15,11 +15,9 @@ from q3asr import Qwen3ASRModel, make_config, synth
 
 pytestmark = pytest.mark.gpu
 
-# Log-mel against the float64 extractor, with the library's own fp32 slaney table (nothing injected).  Measured on
-# MI355X: 1.02e-4 ... 1.11e-4 on the three slices; the excess over 1e-4 sits in isolated bins fed by the table's
-# smallest edge weight (1.2e-4 in filter 53, which moves by 0.2 % between an fp32 and a float64 evaluation of the
-# slaney formula, AudioPreprocessing.swift:23-126).
-MEL_HF_TOL = 1.2e-4
+# Log-mel against the float64 extractor, with the library's own fp32 slaney table (nothing injected): the 1e-4
+# absolute bound of the parity target.  Measured on MI355X: 4.7e-5 / 3.9e-5 / 1.2e-7 on the three slices.
+MEL_HF_TOL = 1e-4
 # bf16 activations between GEMMs on the GPU against fp32 torch
 ENC_RTOL = 3e-2
 LOGIT_RTOL = 4e-2
@@ -62,10 +60,13 @@ def test_mel_residual_against_the_reference_literal_twiddles(tiny_model):
     d_lit, d_exact = np.abs(got - literal), np.abs(got - exact)
     print(f"GPU vs literal-twiddle restatement: max {d_lit.max():.3e}, mean {d_lit.mean():.3e}, share above 1e-4 {(d_lit > 1e-4).mean():.3e}; "
           f"GPU vs exact-twiddle restatement: max {d_exact.max():.3e}")
-    assert d_lit.max() <= 1.5e-3          # measured 7e-4: the literal form's own noise, absent from the exact form
-    assert (d_lit > 1e-4).mean() <= 2e-2  # confined to a small share of the bins
-    assert d_lit.mean() <= 2e-5
-    assert d_exact.max() <= 2.5e-4
+    # measured on MI355X: max 3.0e-3, mean 2.4e-5, 5.8 % of the bins above 1e-4 (against the exact form: max 4.4e-5)
+    assert d_lit.max() <= 4e-3
+    assert (d_lit > 1e-4).mean() <= 8e-2
+    assert d_lit.mean() <= 4e-5
+    assert d_exact.max() <= 1e-4
+    # and all of it is the literal form's own distance from the exact transform, bin for bin
+    assert (d_lit <= np.abs(exact - literal) + 1e-4).all()
 
 
 @pytest.fixture(scope="module")
