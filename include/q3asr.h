@@ -66,6 +66,19 @@ int q3asr_mel_filterbank(q3asr_model* m, float* out);
 int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_utt, int sample_rate, int audio_space,
               float* mel_out, int t_stride, int32_t* n_frames, int out_space);
 
+/* q3asr_mel for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid it).  No counterpart in the reference.  Same kernels and the same result as q3asr_mel on device buffers, but
+ * no hipMalloc / hipFree / host-to-device copy happens inside: what q3asr_mel takes from the model's workspace (offsets on the
+ * device, the tile list, per-utterance maxima and frame counts) lives in a fixed 132 KB device array that every GPU holds
+ * until the process ends.  Limits of that array: 16 kHz input only, at most 256 utterances and 16 128 tiles of 48 frames
+ * (256 clips of 30 s) per call, at most 600 s per utterance; anything larger is rejected with an error.  audio_dev and
+ * mel_out_dev ([n_utt][128][t_stride] fp32) are device pointers, offsets ([n_utt + 1]) and n_frames ([n_utt]) host
+ * pointers.  stream: a hipStream_t to enqueue on (the call then returns without waiting), or NULL for the model's own
+ * stream (the call then waits, like q3asr_mel).  All calls on one GPU share the array: calls that overlap on one GPU
+ * race (calls through one model are serialised; do not run it from two models on one GPU at once). */
+int q3asr_mel_noalloc(q3asr_model* m, const float* audio_dev, const int64_t* offsets, int n_utt, float* mel_out_dev, int t_stride,
+                      int32_t* n_frames, void* stream);
+
 /* Qwen3AudioEncoder.callAsFunction (AudioEncoder.swift:325-501), batched.  mel: [n_utt][128][t_stride]
  * as produced by q3asr_mel.  embeds_out: packed [sum N_u][enc_out_dim] fp32; cu_tokens[n_utt+1] (host)
  * receives the row offsets.  getOutputLength (AudioEncoder.swift:254-270) is q3asr_output_length. */

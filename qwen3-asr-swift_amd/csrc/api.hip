@@ -57,6 +57,7 @@ int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
         m->zero_page = m->dalloc<bf16_t>(512);
         HIP_CHECK(hipMemset(m->zero_page, 0, 1024));
         mel_tables_create(m->mel);
+        mel_noalloc_init();
     } catch (...) {
         q3asr_destroy(m);
         throw;
@@ -121,6 +122,18 @@ int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_
     Q3_REQUIRE(m, "mel: null model");
     std::lock_guard<std::mutex> call_lock(m->call_mutex);
     model_mel(m, audio, offsets, n_utt, sample_rate, audio_space, mel_out, t_stride, n_frames, out_space);
+    Q3_API_END
+}
+
+int q3asr_mel_noalloc(q3asr_model* m, const float* audio_dev, const int64_t* offsets, int n_utt, float* mel_out_dev, int t_stride,
+                      int32_t* n_frames, void* stream) {
+    Q3_API_BEGIN
+    Q3_REQUIRE(m && audio_dev && offsets && mel_out_dev && n_frames, "mel_noalloc: null argument");
+    std::lock_guard<std::mutex> call_lock(m->call_mutex);
+    HIP_CHECK(hipSetDevice(m->device));
+    hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+    mel_noalloc_run(m->mel, audio_dev, offsets, n_utt, mel_out_dev, t_stride, n_frames, s);
+    if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     Q3_API_END
 }
 

@@ -32,3 +32,12 @@ void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, co
                 const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work = 0);
 // In-place clamp / scale of rows [0, frames_out[u]) with the per-utterance maximum.
 void launch_mel_normalize(float* out, int B, int t_stride, const int* d_frames_out, const unsigned* d_max, hipStream_t s);
+
+// Allocation-free log-mel of 16 kHz audio resident in device memory (limits of its fixed device scratch below).
+// mel_noalloc_init: once per device, with that device current (looks up the scratch array's device address).
+// mel_noalloc_run: enqueues the kernels on stream s; does not wait for them.
+constexpr int MEL_NOALLOC_MAX_UTT = 256;
+constexpr int64_t MEL_NOALLOC_MAX_SAMPLES = 16000 * 600;   // per utterance (frames past 30 s only feed the maximum)
+void mel_noalloc_init();
+void mel_noalloc_run(const MelTables& t, const float* audio_dev, const int64_t* offsets_host, int n_utt, float* mel_out_dev,
+                     int t_stride, int32_t* n_frames_host, hipStream_t s);

@@ -482,3 +482,112 @@ void launch_mel_normalize(float* out, int B, int t_stride, const int* d_frames_o
     hipLaunchKernelGGL(mel_normalize_kernel, dim3(MEL_NMELS, B), dim3(256), 0, s, out, t_stride, d_frames_out, d_max);
     HIP_CHECK(hipGetLastError());
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Log-mel without any allocation, for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses
+// that forbid it).  Same kernels as the allocating path; what that path takes from the model's workspace (utterance
+// offsets and lengths on the device, the tile list, the per-utterance running maximum, the frame counts) lives in a
+// fixed file-scope device array instead.  Every GPU holds its own copy of the array at its own address until the
+// process ends; all calls on one GPU share it, so calls that overlap on one GPU race (calls through one model are
+// serialised by the library; two models on one GPU must not run this entry point at the same time).
+namespace {
+
+constexpr int NOALLOC_MAX_UTT = MEL_NOALLOC_MAX_UTT;
+constexpr int NOALLOC_MAX_TILES = NOALLOC_MAX_UTT * ((MEL_MAX_FRAMES + 1 + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES);   // 63 per 30 s clip
+
+struct NoAllocScratch {
+    int64_t off[NOALLOC_MAX_UTT];
+    int64_t len[NOALLOC_MAX_UTT];
+    unsigned dmax[NOALLOC_MAX_UTT];
+    int frames[NOALLOC_MAX_UTT];
+    int tile_utt[NOALLOC_MAX_TILES];
+    int tile_f0[NOALLOC_MAX_TILES];
+};
+static_assert(sizeof(NoAllocScratch) <= 160 * 1024, "scratch is meant to stay modest");
+
+// 135 KB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the device address is looked up
+// once per device and every use below goes through that pointer.
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+PerDeviceOnce g_scratch_once;
+NoAllocScratch* g_scratch_ptr[PerDeviceOnce::MAX_DEVICES];
+
+struct OffsetsArg {   // utterance boundaries by value in the kernel arguments: no host-to-device copy is needed
+    int64_t v[NOALLOC_MAX_UTT + 1];
+};
+
+// Fills the scratch for one call: offsets, lengths, frame counts, a zeroed maximum, and the tile list in utterance
+// order (the same list the allocating path builds on the host).
+__global__ __launch_bounds__(256) void mel_noalloc_setup_kernel(OffsetsArg offs, int n_utt, NoAllocScratch* sc) {
+    __shared__ int tile0[NOALLOC_MAX_UTT + 1];
+    const int tid = threadIdx.x;
+    for (int u = tid; u < n_utt; u += 256) {
+        const int64_t n = offs.v[u + 1] - offs.v[u];
+        sc->off[u] = offs.v[u];
+        sc->len[u] = n;
+        sc->dmax[u] = 0u;
+        int t = (int)(n / MEL_HOP);                      // frames returned: min(n / 160, 3000)
+        sc->frames[u] = t > MEL_MAX_FRAMES ? MEL_MAX_FRAMES : t;
+    }
+    if (tid == 0) {
+        int acc = 0;
+        for (int u = 0; u < n_utt; ++u) {
+            tile0[u] = acc;
+            const int total = (int)((offs.v[u + 1] - offs.v[u]) / MEL_HOP) + 1;
+            acc += (total + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES;
+        }
+        tile0[n_utt] = acc;
+    }
+    __syncthreads();
+    for (int u = 0; u < n_utt; ++u)
+        for (int i = tile0[u] + tid; i < tile0[u + 1]; i += 256) {
+            sc->tile_utt[i] = u;
+            sc->tile_f0[i] = (i - tile0[u]) * MEL_TILE_FRAMES;
+        }
+}
+
+}  // namespace
+
+void mel_noalloc_init() {
+    g_scratch_once.run([&] {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        void* p = nullptr;
+        HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[dev] = (NoAllocScratch*)p;
+        HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES));
+    });
+}
+
+void mel_noalloc_run(const MelTables& t, const float* audio_dev, const int64_t* offsets_host, int n_utt, float* mel_out_dev,
+                     int t_stride, int32_t* n_frames_host, hipStream_t s) {
+    Q3_REQUIRE(n_utt >= 1 && n_utt <= NOALLOC_MAX_UTT,
+               "mel_noalloc: between 1 and " + std::to_string(NOALLOC_MAX_UTT) + " utterances per call (fixed scratch)");
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    NoAllocScratch* sc = g_scratch_ptr[dev];
+    Q3_REQUIRE(sc != nullptr, "mel_noalloc: the scratch address of this device was not set up");
+    OffsetsArg offs;
+    int64_t tiles = 0;
+    int tmax = 1;
+    double bytes = 0;
+    offs.v[0] = offsets_host[0];
+    for (int u = 0; u < n_utt; ++u) {
+        offs.v[u + 1] = offsets_host[u + 1];
+        const int64_t n = offsets_host[u + 1] - offsets_host[u];
+        Q3_REQUIRE(n >= 0, "mel_noalloc: offsets must be non-decreasing");
+        Q3_REQUIRE(n <= (int64_t)MEL_NOALLOC_MAX_SAMPLES, "mel_noalloc: an utterance is longer than " +
+                                                              std::to_string(MEL_NOALLOC_MAX_SAMPLES / 16000) + " s (fixed scratch)");
+        tiles += (mel_frames_total(n) + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES;
+        n_frames_host[u] = mel_frames_out(n);
+        tmax = std::max(tmax, mel_frames_out(n));
+        bytes += 4.0 * (double)n + 4.0 * MEL_NMELS * (double)mel_frames_out(n);
+    }
+    Q3_REQUIRE(tiles <= NOALLOC_MAX_TILES, "mel_noalloc: too much audio for the fixed scratch (at most " +
+                                               std::to_string(NOALLOC_MAX_TILES) + " tiles of 48 frames per call)");
+    Q3_REQUIRE(t_stride >= tmax, "mel_noalloc: t_stride is smaller than the longest utterance's frame count");
+    hipLaunchKernelGGL(mel_noalloc_setup_kernel, dim3(1), dim3(256), 0, s, offs, n_utt, sc);
+    HIP_CHECK(hipGetLastError());
+    launch_mel(t, audio_dev, sc->off, sc->len, sc->tile_utt, sc->tile_f0, (int)tiles, mel_out_dev, t_stride, sc->dmax, s, bytes);
+    launch_mel_normalize(mel_out_dev, n_utt, t_stride, sc->frames, sc->dmax, s);
+}

@@ -42,7 +42,7 @@ EXPORTS = [
     "q3asr_last_error", "q3asr_create", "q3asr_destroy", "q3asr_load_tensor", "q3asr_finalize", "q3asr_mel_filterbank",
     "q3asr_mel", "q3asr_encode", "q3asr_output_length", "q3asr_transcribe_tokens", "q3asr_op_gemm", "q3asr_op_gemm_q4",
     "q3asr_op_attention", "q3asr_profile_start", "q3asr_profile_stop", "q3asr_op_gemm_time", "q3asr_op_greedy_rules",
-    "q3asr_op_read_bandwidth", "q3asr_op_mfma_f32_rate", "q3asr_workspace_bytes",
+    "q3asr_op_read_bandwidth", "q3asr_op_mfma_f32_rate", "q3asr_workspace_bytes", "q3asr_mel_noalloc",
 ]
 
 
@@ -60,6 +60,7 @@ def load():
     lib.q3asr_finalize.argtypes = [c_void_p]
     lib.q3asr_mel_filterbank.argtypes = [c_void_p, c_void_p]
     lib.q3asr_mel.argtypes = [c_void_p, c_void_p, P(ctypes.c_int64), c_int, c_int, c_int, c_void_p, c_int, P(ctypes.c_int32), c_int]
+    lib.q3asr_mel_noalloc.argtypes = [c_void_p, c_void_p, P(ctypes.c_int64), c_int, c_void_p, c_int, P(ctypes.c_int32), c_void_p]
     lib.q3asr_encode.argtypes = [c_void_p, c_void_p, c_int, P(ctypes.c_int32), c_int, c_int, c_void_p, ctypes.c_int64,
                                  P(ctypes.c_int32), c_int]
     lib.q3asr_output_length.argtypes = [c_void_p, c_int]

@@ -118,6 +118,17 @@ class WhisperFeatureExtractor:
         return nfr
 
 
+    def process_device_noalloc(self, audio_ptr, offsets, out_ptr, t_stride=3000, stream=None):
+        """process_device through the entry point that allocates nothing (fixed device scratch; 16 kHz, at most 256
+        utterances per call).  stream: a hipStream_t address to enqueue on without waiting, or None."""
+        m = self._m
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        nfr = np.zeros(len(off) - 1, dtype=np.int32)
+        _lib.check(m._lib, m._lib.q3asr_mel_noalloc(m._h, audio_ptr, _ptr(off, ctypes.c_int64), len(off) - 1, out_ptr, int(t_stride),
+                                                    _ptr(nfr, ctypes.c_int32), stream))
+        return nfr
+
+
 class Qwen3AudioEncoder:
     """AudioEncoder.swift:173-502."""
 
