@@ -58,8 +58,8 @@ public final class Q3Backend {
         var out = [Float](repeating: 0, count: 128 * 3000)
         var frames: Int32 = 0
         let rc = audio.withUnsafeBufferPointer { a in
-            q3asr_mel(handle, a.baseAddress, &offsets, 1, Int32(sampleRate), Int32(Q3ASR_HOST.rawValue), &out, 3000, &frames,
-                      Int32(Q3ASR_HOST.rawValue))
+            q3asr_mel(handle, a.baseAddress, &offsets, 1, Int32(sampleRate), Int32(Q3ASR_HOST), &out, 3000, &frames,
+                      Int32(Q3ASR_HOST))
         }
         guard rc == 0 else { throw Q3Error.last() }
         return (out, Int(frames))
@@ -81,7 +81,7 @@ public final class Q3Backend {
             langIds.withUnsafeBufferPointer { li in langOff.withUnsafeBufferPointer { lo in
                 var req = q3asr_request()
                 req.audio = a.baseAddress; req.offsets = o.baseAddress; req.n_utt = Int32(clips.count)
-                req.sample_rate = Int32(sampleRate); req.audio_space = Int32(Q3ASR_HOST.rawValue)
+                req.sample_rate = Int32(sampleRate); req.audio_space = Int32(Q3ASR_HOST)
                 if languagePrefixes != nil { req.lang_ids = li.baseAddress; req.lang_offsets = lo.baseAddress }
                 req.max_tokens = Int32(maxTokens); req.stop_rules = 1
                 var res = q3asr_result()

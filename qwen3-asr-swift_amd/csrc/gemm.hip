@@ -26,8 +26,9 @@ namespace {
 constexpr int gemm_stages(int mt, int nt) { return (mt == 4 && nt == 4) ? 2 : (mt == 2 && nt == 2) ? 4 : 3; }
 
 struct ConvRow {
-    int64_t base;
-    int iy0, ix0, wv;
+    int64_t base;    // element offset of the row's patch origin (input row iy0, column ix0, channel 0): may point before the image
+    unsigned valid;  // bit t set: tap t = kh * 3 + kw of this output position lies inside the (valid part of the) image
+    int tap, ci;     // kernel tap and input channel of this thread's 8-channel chunk in the K tile staged next
 };
 
 template <int MT, int NT, int AMODE, int OUT, int WFMT>
@@ -84,10 +85,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             const int hw = p.Hout * p.Wout;
             const int chunk = m / hw, rem = m - chunk * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            crow[q].base = (int64_t)chunk * p.Hin * p.Win * p.Cin;
-            crow[q].iy0 = 2 * oy - 1;
-            crow[q].ix0 = 2 * ox - 1;
-            crow[q].wv = min(p.Win, p.win_valid ? p.win_valid[chunk] : p.Win);
+            const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+            const int wv = min(p.Win, p.win_valid ? p.win_valid[chunk] : p.Win);
+            crow[q].base = ((int64_t)chunk * p.Hin + iy0) * p.Win * p.Cin + (int64_t)ix0 * p.Cin;
+            unsigned valid = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < wv) valid |= 1u << t;
+            }
+            crow[q].valid = valid;
+            // K is ordered (kh, kw, cin); Cin is a multiple of 8, so a 16-byte chunk never straddles two taps.  The K
+            // tiles are staged in ascending order, so (tap, ci) advance by 64 channels per stage call: no division in the loop.
+            const int k0 = kt0 * 64 + a_koff[q];
+            crow[q].tap = k0 / p.Cin;
+            crow[q].ci = k0 - crow[q].tap * p.Cin;
         }
     }
     int w_voff[WP];
@@ -118,13 +130,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         } else {
 #pragma unroll
             for (int q = 0; q < AP; ++q) {
-                const int k0 = kbase + a_koff[q];
-                const int khw = k0 / p.Cin, ci = k0 - khw * p.Cin;
-                const int kh = khw / 3, kw = khw - kh * 3;
-                const int iy = crow[q].iy0 + kh, ix = crow[q].ix0 + kw;
-                const bool ok = (k0 < p.K) && iy >= 0 && iy < p.Hin && ix >= 0 && ix < crow[q].wv;
-                const bf16_t* src = ok ? p.A + crow[q].base + ((int64_t)iy * p.Win + ix) * p.Cin + ci : p.zero;
+                const int tap = crow[q].tap, ci = crow[q].ci;
+                const bool ok = tap < 9 && ((crow[q].valid >> tap) & 1u);       // tap >= 9: past the end of K
+                const int kh = (tap * 11) >> 5;                                  // tap / 3 for tap < 32
+                const int toff = (kh * p.Win + (tap - 3 * kh)) * p.Cin + ci;
+                const bf16_t* src = ok ? p.A + crow[q].base + toff : p.zero;
                 __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sa + (q * 256 + uwave * 64) * 16), 16, 0, 0);
+                int nci = ci + 64, ntap = tap;
+                while (nci >= p.Cin) { nci -= p.Cin; ++ntap; }                   // at most once when Cin >= 64
+                crow[q].ci = nci;
+                crow[q].tap = ntap;
             }
         }
         if constexpr (WFMT == W_BF16) {

@@ -27,20 +27,35 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Params p) {
         patch[kh][j] = v;
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 256) {
-        float w[9];
+    // The kernel is bound by its 3 MB of output per chunk: a thread owns 8 consecutive channels (one 16-byte store per
+    // output position) and walks the 50 output columns with the other threads of its channel group.
+    const int ncg = p.C >> 3, lanes = 256 / ncg;   // channel groups; output columns computed side by side
+    const int cg = tid % ncg, ox0 = tid / ncg;
+    if (ox0 >= lanes) return;
+    float w[8][9], b[8];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) w[k] = p.w[c * 9 + k];
-        const float b = p.bias[c];
-        bf16_t* o = p.out + ((int64_t)(ch * 64 + oy) * 50) * p.C + c;
-        for (int ox = 0; ox < 50; ++ox) {
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[j][k] = p.w[(cg * 8 + j) * 9 + k];
+        b[j] = p.bias[cg * 8 + j];
+    }
+    bf16_t* o = p.out + ((int64_t)(ch * 64 + oy) * 50) * p.C + cg * 8;
+    for (int ox = ox0; ox < 50; ox += lanes) {
+        float x[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = patch[kh][2 * ox + kw];
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
             float acc = 0.f;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], patch[kh][2 * ox + kw], acc);
-            o[(int64_t)ox * p.C] = f32_to_bf16(gelu_erf(acc + b));
+            for (int k = 0; k < 9; ++k) acc = fmaf(w[j][k], x[k], acc);
+            y[j] = gelu_erf(acc + b[j]);
         }
+        *(uint4*)(o + (int64_t)ox * p.C) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                                                      pack_bf16x2(y[6], y[7]));
     }
 }
 
@@ -496,6 +511,7 @@ void launch_swiglu_reduce(const float* slab, int nslab, int64_t slab_stride, int
 
 void launch_conv1(const Conv1Params& p, hipStream_t s) {
     if (p.n_chunks <= 0) return;
+    Q3_REQUIRE(p.C % 8 == 0 && p.C >= 8 && p.C <= 2048, "conv1: channels must be a multiple of 8 within 2048");
     hipLaunchKernelGGL(conv1_kernel, dim3(64, p.n_chunks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
