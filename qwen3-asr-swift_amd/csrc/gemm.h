@@ -45,6 +45,8 @@ struct GemmParams {
 void launch_gemm(const GemmParams& p, GemmAMode amode, GemmOut out, GemmWFmt wfmt, int tile, hipStream_t s);
 // the 256x256 8-wave kernel (gemm256.hip); reached through launch_gemm
 void launch_gemm256(const GemmParams& p, GemmOut out, hipStream_t s);
+// the same kernel as an implicit-GEMM 3x3 stride-2 convolution (bf16 output); reached through launch_gemm
+void launch_gemm256_conv(const GemmParams& p, hipStream_t s);
 // number of 16*NT-column partial blocks the OUT_ARGMAX epilogue writes per row for a given N / tile
 int gemm_argmax_parts(int N, int tile);
 int gemm_pick_tile(int M, int N);

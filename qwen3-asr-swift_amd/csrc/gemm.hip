@@ -435,10 +435,16 @@ void launch_gemm(const GemmParams& p, GemmAMode amode, GemmOut out, GemmWFmt wfm
     if (wfmt == W_Q4) Q3_REQUIRE(p.qgroup == 64 && p.K % 64 == 0, "gemm: q4 needs group 64 and K multiple of 64");
     if (out == OUT_SWIGLU) Q3_REQUIRE(p.N % 16 == 0, "gemm: SwiGLU needs N multiple of 16");
     if (out != OUT_SLAB) Q3_REQUIRE(p.ksplit == 1, "gemm: split-K only with slab output");
-    const bool can256 = amode == A_PLAIN && wfmt == W_BF16;
+    const bool conv256 = amode == A_CONV3X3S2 && wfmt == W_BF16 && out == OUT_BF16;
+    const bool can256 = (amode == A_PLAIN && wfmt == W_BF16) || conv256;
     if (tile < 0) {
         tile = gemm_pick_tile(p.M, p.N);
         if (tile == 3 && !can256) tile = 0;
+    }
+    if (tile == 3 && conv256) {
+        Q3_REQUIRE(p.K == 9 * p.Cin && p.Cin % 8 == 0, "gemm: conv K must be 9*Cin, Cin multiple of 8");
+        launch_gemm256_conv(p, s);
+        return;
     }
     if (tile == 3) {
         Q3_REQUIRE(can256, "gemm: the 256x256 tile needs plain rows and bf16 weights");

@@ -36,7 +36,12 @@ constexpr int UNIT = 128 * 128;  // bytes of one staging unit
 constexpr int BUF = 4 * UNIT;    // A0 | A1 | W0 | W1
 constexpr int LDS_BYTES = 2 * BUF;
 
-template <int OUT>
+// AMODE A_CONV3X3S2: implicit-GEMM 3x3 stride-2 pad-1 convolution over an NHWC image.  K runs over 9 taps x Cin
+// channels, each tap padded to whole 64-channel K tiles (for Cin = 480: 8 tiles, the last one half empty, +6.7 % MFMA
+// work) so that a K tile never straddles two taps: the tap's pixel offset and the channel offset are then uniform and
+// ride in the scalar offset of the buffer loads, a lane's own patch origin is a fixed per-lane offset exactly like a
+// plain row, and padding or channel-tail lanes are sent out of the descriptor's range (they read as zero).
+template <int OUT, int AMODE>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -52,7 +57,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr int GROUP = 8;
     const int per_group = GROUP * tiles_n;
 
-    const int nk_total = (p.K + 63) >> 6;
+    constexpr bool CONV = AMODE == A_CONV3X3S2;
+    const int tpt = CONV ? (p.Cin + 63) >> 6 : 1;            // K tiles per tap
+    const int tpt_magic = CONV ? (65536 + tpt - 1) / tpt : 0;  // kt / tpt == (kt * magic) >> 16 for kt < 4096
+    const int nk_total = CONV ? 9 * tpt : (p.K + 63) >> 6;
     const int per = (nk_total + p.ksplit - 1) / p.ksplit;
     const int kt0 = blockIdx.z * per, kt1 = min(nk_total, kt0 + per);
 
@@ -67,6 +75,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     constexpr int BUF_RANGE = 0x40000000, BUF_OOB = 0x7f000000;
     int m0 = 0, n0 = 0, tn = 0;
     int a_off[2][2], w_off[2][2];  // [q][unit], in bytes
+    unsigned a_valid[2][2];        // CONV: bit t set when tap t of the lane's output position lies inside the image
     __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
     auto setup = [&](int b) {
         const int q8 = total >> 3, r8 = total & 7, x = b & 7;
@@ -82,14 +91,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 // A unit u, LDS row q*64 + srow  <-  tile row q*128 + u*64 + srow   (q = reading wave's row half)
-                const int m = min(m0 + q * 128 + u * 64 + srow, p.M - 1) - m0;
-                a_off[q][u] = (m * (int)p.lda + koff) * 2;
+                if constexpr (CONV) {
+                    const int hw = p.Hout * p.Wout, img = p.Hin * p.Win * p.Cin;
+                    const int chunk0 = m0 / hw;                       // the descriptor is based one row and one pixel before this chunk
+                    const int mm = min(m0 + q * 128 + u * 64 + srow, p.M - 1);
+                    const int chunk = mm / hw, rem = mm - chunk * hw;
+                    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                    const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+                    const int wv = min(p.Win, p.win_valid ? p.win_valid[chunk] : p.Win);
+                    a_off[q][u] = ((chunk - chunk0) * img + ((iy0 + 1) * p.Win + ix0 + 1) * p.Cin + koff) * 2;
+                    unsigned valid = 0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < wv) valid |= 1u << t;
+                    }
+                    a_valid[q][u] = valid;
+                } else {
+                    const int m = min(m0 + q * 128 + u * 64 + srow, p.M - 1) - m0;
+                    a_off[q][u] = (m * (int)p.lda + koff) * 2;
+                }
                 // W unit u, LDS row rho = q*64 + srow = wc*32 + j*16 + i  <-  tile row wc*64 + (i>>2)*16 + u*8 + j*4 + (i&3)
                 const int rho = q * 64 + srow, i = rho & 15, j = (rho >> 4) & 1, c = rho >> 5;
                 const int n = min(n0 + c * 64 + (i >> 2) * 16 + u * 8 + j * 4 + (i & 3), p.N - 1) - n0;
                 w_off[q][u] = (n * p.K + koff) * 2;
             }
-        a_rsrc = uniform_buffer(p.A + (int64_t)m0 * p.lda, BUF_RANGE);
+        if constexpr (CONV)
+            a_rsrc = uniform_buffer(p.A + (int64_t)(m0 / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin - (int64_t)(p.Win + 1) * p.Cin, BUF_RANGE);
+        else
+            a_rsrc = uniform_buffer(p.A + (int64_t)m0 * p.lda, BUF_RANGE);
         w_rsrc = uniform_buffer((const bf16_t*)p.W + (int64_t)n0 * p.K, BUF_RANGE);
     };
     const int lds_lane0 = uwave * 64 * 16;
@@ -97,8 +127,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // unit: 0 = A0, 1 = A1, 2 = W0, 3 = W1
     auto stage = [&](int buf, int unit, int kt) {
         char* dst = smem + buf * BUF + unit * UNIT + lds_lane0;
+        const bool past = kt >= kt1;  // wave-uniform
+        if constexpr (CONV) {
+            const int tap = (kt * tpt_magic) >> 16, ci0 = (kt - tap * tpt) * 64;   // wave-uniform
+            const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
+            const bool ch_out = ci0 + koff >= p.Cin;                                // channel tail of the tap's last K tile
+            const int a_s = past ? 0 : (((kh - 1) * p.Win + kw - 1) * p.Cin + ci0 + (p.Win + 1) * p.Cin) * 2;
+            const int w_s = past ? 0 : (tap * p.Cin + ci0) * 2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (unit < 2) {
+                    const bool ok = !past && !ch_out && ((a_valid[q][unit] >> tap) & 1u);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, LDS_PTR(dst + q * 512 * 16), 16, ok ? a_off[q][unit] : BUF_OOB, a_s, 0, 0);
+                } else {
+                    const bool ok = !past && !ch_out;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(dst + q * 512 * 16), 16, ok ? w_off[q][unit - 2] : BUF_OOB, w_s, 0, 0);
+                }
+            }
+            return;
+        }
         const int kbase = kt * 64;
-        const bool past = kt >= kt1, tail = kbase + 64 > p.K;  // wave-uniform
+        const bool tail = kbase + 64 > p.K;
         const bool masked = past || (tail && kbase + koff >= p.K);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -309,20 +358,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 // One workgroup per CU, rounded down to a multiple of 8 so that a workgroup's virtual block indices all map to its XCD.
 int persistent_grid() { return std::max(8, device_cus() & ~7); }
 
-template <int OUT>
+template <int OUT, int AMODE = A_PLAIN>
 void launch_o(const GemmParams& p, hipStream_t s) {
     const int tiles = cdiv(p.M, 256) * cdiv(p.N, 256);
     static PerDeviceOnce once;
-    once.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); });
-    static const std::string name = "gemm256_kernel<" + std::to_string(OUT) + ">";
+    once.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)gemm256_kernel<OUT, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); });
+    static const std::string name = std::string(AMODE == A_PLAIN ? "gemm256_kernel<" : "gemm256_conv_kernel<") + std::to_string(OUT) + ">";
     {
         ProfScope ps(name.c_str(), 2.0 * p.M * p.N * p.K, s);
-        hipLaunchKernelGGL((gemm256_kernel<OUT>), dim3(std::min(tiles, persistent_grid()), 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
+        hipLaunchKernelGGL((gemm256_kernel<OUT, AMODE>), dim3(std::min(tiles, persistent_grid()), 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
     }
     HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace
+
+void launch_gemm256_conv(const GemmParams& p, hipStream_t s) {
+    // per-lane offsets are taken from the tile's first chunk: the chunks a 256-row tile can touch must stay inside 1 GB
+    const int64_t chunks_per_tile = 256 / (p.Hout * p.Wout) + 2;
+    Q3_REQUIRE(p.Hout * p.Wout > 0 && (chunks_per_tile + 1) * p.Hin * p.Win * p.Cin * 2 < (1ll << 30) && 257ll * p.K * 2 < (1ll << 30) &&
+                   p.ksplit == 1 && (p.Cin + 63) / 64 * 9 < 4096,
+               "gemm256: convolution shape outside the kernel's addressing range");
+    launch_o<OUT_BF16, A_CONV3X3S2>(p, s);
+}
 
 void launch_gemm256(const GemmParams& p, GemmOut out, hipStream_t s) {
     // staging offsets are byte offsets from a tile's first row and must stay inside the descriptors' 1 GB range
