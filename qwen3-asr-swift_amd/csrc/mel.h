@@ -4,11 +4,11 @@
 #include <vector>
 
 constexpr int MEL_NFFT = 400, MEL_HOP = 160, MEL_NMELS = 128, MEL_NBINS = 201, MEL_MAX_FRAMES = 3000;
-constexpr int MEL_TILE_FRAMES = 48;  // frames per kernel tile (three 16-frame MFMA row tiles)
+constexpr int MEL_TILE_FRAMES = 32;  // frames per kernel tile
 
 struct MelTables {           // device-resident constants, built once per model
-    float* twid = nullptr;   // [26][4][7][64] MFMA B-fragments of the folded DFT, Hann window included
-    float* fb_packed = nullptr;  // non-zero filter weights, filter after filter, padded to a multiple of 64
+    float* twid = nullptr;   // Hann window [400], inter-stage twiddles [25][8] (cos, -sin), untangling twiddles [101] (cos, sin)
+    float* fb_packed = nullptr;  // filterbank as fp32 MFMA B-fragments of the banded column tiles: [2 sets][28 steps][64 lanes]
     std::vector<float> host_fb;  // dense [128][201] filterbank (host copy, for inspection / tests)
 };
 

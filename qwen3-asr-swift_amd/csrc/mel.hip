@@ -1,41 +1,43 @@
 // Log-mel frontend for gfx950.
 //
-// Restates WhisperFeatureExtractor (reference: Sources/Qwen3ASR/AudioPreprocessing.swift:131-324).
-// Work is cut into tiles of 48 frames of one utterance; persistent workgroups (one per CU) loop over the tiles.
-// The 7 920 samples a tile covers are staged once in LDS (coalesced, reflect padding resolved on load).  Because the
-// frame is real, the 400-point DFT folds to Re X[k] = sum_{n<=200} h[n](x[n] + x[400-n]) cos(2 pi k n / 400) and
-// Im X[k] = -sum h[n](x[n] - x[400-n]) sin(...); splitting those sums into even and odd n gives four
-// [frames x 101] x [101 x 101] real products (Ce, Co, Se, So over bins 0..100) from which bin k is
-// (Ce + Co, Se + So) and bin 200 - k is (Ce - Co, Se - So): a quarter of the direct DFT's multiplies,
-// evaluated on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, an fp32 fma chain) with the Hann window folded into the
-// twiddle tables.  The difference form loses accuracy only where bin 200 - k is far weaker than bin k: relative error
-// ~6e-8 * |X[k]| / |X[200-k]|, i.e. < 1e-5 of log-mel for a 60 dB spread between the halves of the spectrum.
-// Seven waves transform (one 16-bin tile each, twiddles resident in registers); an eighth wave applies the slaney
-// filterbank, log10 and the per-utterance running maximum (wave reduction + one atomic per tile) to the previous
-// tile's power spectrum and stages the next tile's samples, so neither phase waits for the other.  Output is the raw
-// log10 mel; the max-8 clamp and (x+4)/4 scale need the utterance-wide maximum and are applied by the consumer
-// (conv1) or by launch_mel_normalize for callers that want the reference's exact output tensor.
+// Restates WhisperFeatureExtractor (reference: Sources/Qwen3ASR/AudioPreprocessing.swift:131-324): reflect padding, periodic
+// Hann window, 201-bin power spectrum of 400-sample frames every 160 samples, slaney filterbank, log10.  The reference
+// evaluates the spectrum as a direct DFT (:184-209); here it is an FFT on the vector ALU, which is what makes the stage
+// bandwidth-bound: the 400 real samples of a frame are packed into 200 complex values z[m] = x[2m] + i x[2m+1], a
+// 200-point complex FFT is taken as 8 x 25 (one radix-8 butterfly per (frame, residue mod 25), twiddles, one 25-point
+// transform per (frame, residue mod 8), itself 5 x 5 in registers), and the real spectrum is untangled from Z[k] and
+// Z[200-k].  About 10 kFLOP per frame instead of 160 kFLOP for the folded direct DFT.
+//
+// Work is cut into tiles of 32 frames of one utterance; persistent workgroups of 256 threads (two per CU, 79 KB of LDS each)
+// loop over the tiles.  Per tile: the 5 360 samples it covers are staged in LDS (fetched into registers during the previous
+// tile's arithmetic); phase 1 windows the samples and runs the 800 radix-8 butterflies; phase 2 the 256 25-point transforms;
+// phase 3 untangles the 101 bin pairs of every frame into power values; phase 4 applies the slaney filterbank with
+// compile-time filter supports, log10, the per-utterance running maximum (wave reduction + one atomic per wave) and stores
+// [mel][frame] rows, 32 consecutive frames per store.  Output is the raw log10 mel; the max-8 clamp and (x+4)/4 scale need the
+// utterance-wide maximum and are applied by the consumer (conv1) or by launch_mel_normalize for callers that want the
+// reference's exact output tensor.  Twiddles are rounded from double; the window multiplies the samples in fp32 as the
+// reference does (:161-164, 195-197).
 #include "mel.h"
 #include "prof.h"
 #include <algorithm>
 #include <cmath>
 #include <vector>
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-
 namespace {
 
-constexpr int KSTEPS = 26;     // 104 >= 101 folded taps of each parity, 4 per MFMA
-constexpr int NTILES = 7;      // 112 >= 101 bins
-constexpr int MTILES = MEL_TILE_FRAMES / 16;
-constexpr int MEL_THREADS = 64 * (NTILES + 1);  // one transform wave per 16-bin tile + one filterbank / staging wave
-constexpr int SAMPLES = MEL_TILE_FRAMES * MEL_HOP + (MEL_NFFT - MEL_HOP) + 1;  // 7921
-constexpr int SREG = 8032;     // skewed sample image: skew(7920) = 8017
-constexpr int POW_STRIDE = MEL_NBINS;
-constexpr int POW_N = MEL_TILE_FRAMES * POW_STRIDE + 16;
-constexpr int HANN_N = 208;
-constexpr int MEL_LDS_BYTES = (2 * SREG + 2 * POW_N) * 4;  // two sample images, two power spectra: 142 KB
+constexpr int TF = MEL_TILE_FRAMES;                               // 32 frames per tile
+constexpr int MEL_THREADS = 256;
+constexpr int SAMPLES = (TF - 1) * MEL_HOP + MEL_NFFT;            // 5360 samples under a tile's frames
+constexpr int XS_N = 6432;                                        // sample image, later the power rows [32][201]
+constexpr int POW_STRIDE = MEL_NBINS;                             // 201: odd, so frames fall on distinct banks
+constexpr int ZS = 200;                                           // complex values per frame row (see phase 2 for the bank argument)
+constexpr int Z_N = TF * ZS;
+// tables (floats): Hann window [400] | W200^(n2 k1) as (cos, -sin) pairs [8][25] | exp(-i pi k / 200) as (cos, -sin) pairs [101]
+constexpr int TAB_HANN = 0, TAB_TW = 400, TAB_UW = 800, TAB_N = 1002;
+constexpr int MEL_LDS_BYTES = (XS_N + 2 * Z_N + TAB_N + 6) * 4;  // 80 960 bytes: two workgroups per CU
+static_assert(XS_N >= SAMPLES && XS_N >= TF * POW_STRIDE, "sample image and power rows share one region");
+static_assert(MEL_LDS_BYTES <= 80 * 1024, "two workgroups must fit a CU's 160 KB");
+constexpr int NLOAD = (SAMPLES + MEL_THREADS - 1) / MEL_THREADS;  // 21 samples per thread per tile
 
 // Support of the slaney filters at 16 kHz / 400-point FFT / 128 bins (AudioPreprocessing.swift:23-126): first FFT bin and
 // number of bins of every filter.  Fixed by the reference's constants; mel_tables_create checks the computed filterbank
@@ -50,18 +52,6 @@ constexpr unsigned char FB_W[MEL_NMELS] = {
     1, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 2, 1, 1, 2, 1, 1, 2, 1, 1, 2, 2, 2, 2, 1, 1, 2, 2, 2, 2, 2,
     2, 2, 2, 3, 3, 2, 2, 2, 3, 3, 2, 3, 3, 2, 3, 3, 3, 3, 3, 4, 3, 3, 4, 4, 4, 3, 3, 4, 4, 5, 5, 4,
     4, 5, 5, 4, 5, 5, 5, 6, 5, 5, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 8, 7, 7, 8, 9, 9, 8, 9, 9, 9, 9};
-constexpr int fb_offset(int m) {  // position of filter m's first weight in the packed weight list
-    int o = 0;
-    for (int i = 0; i < m; ++i) o += FB_W[i];
-    return o;
-}
-constexpr int FB_TOTAL = fb_offset(MEL_NMELS);       // 394
-constexpr int FB_REGS = (FB_TOTAL + 63) / 64;        // packed weights, one per lane per register
-
-__device__ __forceinline__ int frame_skew(int q) { return 4 * (q >> 1) + (q & 1); }
-// Frame starts (multiples of 160 samples) land on distinct banks for the stride-2 fragment reads.
-__device__ __forceinline__ int skew(int p) { return p + frame_skew(p / MEL_HOP); }
-
 __device__ __forceinline__ unsigned enc_max(float f) {
     const unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -86,275 +76,283 @@ __device__ __forceinline__ TileInfo tile_info(const float* audio, const int64_t*
     return ti;
 }
 
-__device__ __forceinline__ bool tile_is_interior(const TileInfo& ti) {  // no padding inside the tile
-    const int64_t P0 = (int64_t)ti.f0 * MEL_HOP;
-    return P0 >= 200 && P0 + SAMPLES <= ti.n + 200;
-}
-
-// Interior tile: loads this thread's share (samples id, id + STRIDE, ...) into registers; all loads are issued before
-// anything waits on them, and write_tile stores them into a skewed LDS image later.
-template <int N, int STRIDE, int I0>
-__device__ __forceinline__ void fetch_tile(const TileInfo& ti, float (&sv)[N], int id) {
-    const float* xs = ti.x + ((int64_t)ti.f0 * MEL_HOP - 200);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int p = id + (I0 + i) * STRIDE;
-        sv[i] = ((I0 + i + 1) * STRIDE <= SAMPLES || p < SAMPLES) ? xs[p] : 0.f;
-    }
-}
-
-template <int N, int STRIDE, int I0>
-__device__ __forceinline__ void write_tile(const float (&sv)[N], float* dst, int id) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int p = id + (I0 + i) * STRIDE;
-        if ((I0 + i + 1) * STRIDE <= SAMPLES || p < SAMPLES) dst[skew(p)] = sv[i];
-    }
-}
-
-// Tile that touches the reflect padding of 200 samples or the end of the utterance (AudioPreprocessing.swift:134-154):
-// staged directly, BATCH loads at a time.
-template <int BATCH>
-__device__ __forceinline__ void stage_edge_tile(const TileInfo& ti, float* dst, int id, int stride) {
+// This thread's share (samples tid, tid + 256, ...) of a tile's sample window, in the reflect-padded signal
+// (AudioPreprocessing.swift:134-154: 200 samples mirrored at either end, edge-safe for short audio; zero beyond).
+__device__ __forceinline__ void fetch_samples(const TileInfo& ti, float (&sv)[NLOAD], int tid) {
     const int64_t P0 = (int64_t)ti.f0 * MEL_HOP, n = ti.n;
-    for (int p0 = id; p0 < SAMPLES; p0 += BATCH * stride) {
-        float v[BATCH];
+    if (P0 >= 200 && P0 + NLOAD * MEL_THREADS <= n + 200) {   // interior: no padding inside the window (workgroup-uniform)
+        const float* xs = ti.x + (P0 - 200);
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) {
-            const int64_t P = P0 + p0 + i * stride;
-            int64_t idx = P < 200 ? 200 - P : (P < 200 + n ? P - 200 : 2 * n + 198 - P);
-            idx = max(min(idx, n - 1), (int64_t)0);
-            v[i] = (n > 0 && P < n + MEL_NFFT) ? ti.x[idx] : 0.f;
-        }
+        for (int i = 0; i < NLOAD; ++i) sv[i] = xs[tid + i * MEL_THREADS];
+        return;
+    }
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) {
-            const int p = p0 + i * stride;
-            if (p < SAMPLES) dst[skew(p)] = v[i];
-        }
+    for (int i = 0; i < NLOAD; ++i) {
+        const int64_t P = P0 + tid + i * MEL_THREADS;
+        int64_t idx = P < 200 ? 200 - P : (P < 200 + n ? P - 200 : 2 * n + 198 - P);
+        idx = max(min(idx, n - 1), (int64_t)0);
+        sv[i] = (n > 0 && P < n + MEL_NFFT) ? ti.x[idx] : 0.f;
     }
 }
 
-// Filter M applied to the power spectrum row of this lane's frame; weights come from the lane-packed registers.
-template <int M>
-__device__ __forceinline__ float mel_filter(const float* pw, const float (&fbv)[FB_REGS]) {
-    constexpr int lo = FB_LO[M], w = FB_W[M], off = fb_offset(M);
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < w; ++c) {
-        const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fbv[(off + c) >> 6]), (off + c) & 63));
-        sum = fmaf(pw[lo + c], wt, sum);
-    }
-    return sum;
+// The filterbank as a banded matrix product on the fp32 matrix pipe: mel[frame][filter] = sum_bin P[frame][bin] W[bin][filter].
+// A 16-filter column tile only touches the bins between its first filter's lower edge and its last filter's upper edge, so
+// it takes ct_steps() MFMAs of 16 x 16 x 4 instead of 51: 56 steps over the eight column tiles (a dense product needs 408).
+constexpr int ct_lo(int ct) { return FB_LO[16 * ct]; }
+constexpr int ct_hi(int ct) {
+    int hi = 0;
+    for (int m = 16 * ct; m < 16 * ct + 16; ++m) hi = FB_LO[m] + FB_W[m] > hi ? FB_LO[m] + FB_W[m] : hi;
+    return hi;
 }
+constexpr int ct_steps(int ct) { return (ct_hi(ct) - ct_lo(ct) + 3) / 4; }
+// Two sets of column tiles with 28 steps each; wave w works on set w / 2 for the 16 frames of row tile w % 2.
+constexpr int SET_A[3] = {7, 5, 0}, SET_B[5] = {6, 4, 3, 2, 1};
+constexpr int SET_STEPS = 28;
+static_assert(ct_steps(7) + ct_steps(5) + ct_steps(0) == SET_STEPS && ct_steps(6) + ct_steps(4) + ct_steps(3) + ct_steps(2) + ct_steps(1) == SET_STEPS,
+              "the two filter sets must be balanced");
 
-constexpr int MEL_GROUP = 16;  // filters evaluated together: straight-line code, one predicated burst of stores
-
-template <int M0, int J>
-__device__ __forceinline__ void mel_values(const float* pw, const float (&fbv)[FB_REGS], float (&v)[MEL_GROUP]) {
-    if constexpr (J < MEL_GROUP) {
-        // log10 of the clamped filter output (AudioPreprocessing.swift:232-255).  The hardware log2 is accurate to 1 ulp
-        // and the argument is never denormal, so the plain product is within 2e-6 of the correctly rounded value.
-        v[J] = __log2f(fmaxf(mel_filter<M0 + J>(pw, fbv), 1e-10f)) * 0.30102999566398120f;
-        mel_values<M0, J + 1>(pw, fbv, v);
-    }
-}
-
-struct MelOut {
-    float* out;     // this lane's column of the utterance's [128][t_stride] block
+struct MelTileOut {
+    float* out;          // utterance's [128][t_stride] block + first frame of this lane's four
     int t_stride;
-    bool store;
+    int n_store;         // how many of the lane's four frames are returned (0..4)
+    int n_max;           // how many of them count for the running maximum
+    bool vec;            // 16-byte stores allowed
     float vmax;
 };
 
-template <int M0, int M1>
-__device__ __forceinline__ void mel_rows(const float* pw, const float (&fbv)[FB_REGS], MelOut& o) {
-    if constexpr (M0 < M1) {
-        float v[MEL_GROUP];
-        mel_values<M0, 0>(pw, fbv, v);
+// One column tile: CT = tile, OFF = position of its first weight fragment in the wave's register-resident list.
+template <int CT, int OFF>
+__device__ __forceinline__ void mel_col_tile(const float* pw, const float (&bf)[SET_STEPS], int n, MelTileOut& o) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < MEL_GROUP; ++j) o.vmax = fmaxf(o.vmax, v[j]);
-        if (o.store) {
+    for (int s = 0; s < ct_steps(CT); ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[ct_lo(CT) + 4 * s], bf[OFF + s], acc, 0, 0, 0);
+    // log10 of the clamped filter output (AudioPreprocessing.swift:232-255).  The hardware log2 is accurate to 1 ulp
+    // and the argument is never denormal, so the plain product is within 2e-6 of the correctly rounded value.
+    float y[4];
 #pragma unroll
-            for (int j = 0; j < MEL_GROUP; ++j) o.out[(int64_t)(M0 + j) * o.t_stride] = v[j];
-        }
-        mel_rows<M0 + MEL_GROUP, M1>(pw, fbv, o);
+    for (int r = 0; r < 4; ++r) {
+        y[r] = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
+        if (r < o.n_max) o.vmax = fmaxf(o.vmax, y[r]);
+    }
+    float* dst = o.out + (int64_t)(16 * CT + n) * o.t_stride;
+    if (o.vec && o.n_store == 4) {
+        *(float4*)dst = make_float4(y[0], y[1], y[2], y[3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < o.n_store) dst[r] = y[r];
     }
 }
 
-// Persistent workgroups: each takes tiles blockIdx.x, blockIdx.x + gridDim.x, ... of 48 frames.  Waves 0-6 transform: wave w
-// owns bins 16w .. 16w+15 of all four products and keeps their twiddles (4 x 26 fragments) in registers for the whole kernel,
-// so the MFMA loop reads only LDS.  Wave 7 meanwhile turns the previous tile's power spectrum into log-mel rows and stages the
-// next tile's samples; sample image and power spectrum are double buffered and one barrier per tile hands them over.
-__global__ __launch_bounds__(MEL_THREADS) void mel_kernel(const float* __restrict__ audio, const int64_t* __restrict__ d_off,
-                                                          const int64_t* __restrict__ d_len, const int* __restrict__ tile_utt,
-                                                          const int* __restrict__ tile_f0, int n_tiles,
-                                                          const float* __restrict__ twid,
-                                                          const float* __restrict__ fb_packed, float* __restrict__ out,
-                                                          int t_stride, unsigned* __restrict__ d_max) {
+// Complex values live in register pairs (re, im) and all butterfly arithmetic is packed fp32 (v_pk_add / v_pk_mul /
+// v_pk_fma: two lanes of work per instruction, the only way the vector ALU reaches its fp32 rate); multiplications by
+// +-i and complex products are single packed instructions whose operand halves are swapped / negated by op_sel / neg.
+typedef float cpx __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cpx add_mi(cpx x, cpx y) {   // x + (-i) y = (x.r + y.i, x.i - y.r)
+    cpx d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+__device__ __forceinline__ cpx add_pi(cpx x, cpx y) {   // x + (+i) y = (x.r - y.i, x.i + y.r)
+    cpx d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+__device__ __forceinline__ cpx cmul(cpx a, cpx w) {     // a * (w.x + i w.y) = (a.r w.x - a.i w.y, a.i w.x + a.r w.y)
+    cpx t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ cpx splat(float v) { return (cpx){v, v}; }
+
+// Forward 5-point DFT in place (w = exp(-2 pi i / 5)).
+__device__ __forceinline__ void dft5(cpx& x0, cpx& x1, cpx& x2, cpx& x3, cpx& x4) {
+    const cpx C1 = splat(0.30901699437494745f), C2 = splat(-0.8090169943749473f), S1 = splat(0.9510565162951535f), S2 = splat(0.5877852522924732f);
+    const cpx s1 = x1 + x4, s2 = x2 + x3, d1 = x1 - x4, d2 = x2 - x3;
+    const cpx a = x0 + C1 * s1 + C2 * s2;
+    const cpx b = x0 + C2 * s1 + C1 * s2;
+    const cpx p = S1 * d1 + S2 * d2;   // X1 = a - i p, X4 = a + i p
+    const cpx q = S2 * d1 - S1 * d2;   // X2 = b - i q, X3 = b + i q
+    x0 = x0 + s1 + s2;
+    x1 = add_mi(a, p);
+    x4 = add_pi(a, p);
+    x2 = add_mi(b, q);
+    x3 = add_pi(b, q);
+}
+
+// W25^(b c) = exp(-2 pi i b c / 25) for b, c in 1..4 as (cos, -sin), rounded from double.
+__device__ __forceinline__ cpx tw25(cpx a, int b, int c) {
+    constexpr float C[4][4] = {{0.9685831611286311f, 0.8763066800438636f, 0.7289686274214116f, 0.5358267949789965f},
+                               {0.8763066800438636f, 0.5358267949789965f, 0.06279051952931353f, -0.4257792915650727f},
+                               {0.7289686274214116f, 0.06279051952931353f, -0.6374239897486897f, -0.9921147013144778f},
+                               {0.5358267949789965f, -0.4257792915650727f, -0.9921147013144778f, -0.6374239897486895f}};
+    constexpr float S[4][4] = {{-0.2486898871648548f, -0.4817536741017153f, -0.6845471059286886f, -0.8443279255020151f},
+                               {-0.4817536741017153f, -0.8443279255020151f, -0.9980267284282716f, -0.9048270524660195f},
+                               {-0.6845471059286886f, -0.9980267284282716f, -0.7705132427757893f, -0.12533323356430454f},
+                               {-0.8443279255020151f, -0.9048270524660195f, -0.12533323356430454f, 0.7705132427757894f}};
+    return cmul(a, (cpx){C[b - 1][c - 1], S[b - 1][c - 1]});
+}
+
+// Persistent workgroups, each looping over tiles of 32 frames.
+__global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __restrict__ audio, const int64_t* __restrict__ d_off,
+                                                             const int64_t* __restrict__ d_len, const int* __restrict__ tile_utt,
+                                                             const int* __restrict__ tile_f0, int n_tiles,
+                                                             const float* __restrict__ tables,
+                                                             const float* __restrict__ fb_frags, float* __restrict__ out,
+                                                             int t_stride, unsigned* __restrict__ d_max, int vec_ok) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* pwr = sm + 2 * SREG;
+    float* xs = sm;                           // samples of the tile; from phase 3 on the power rows [32][201]
+    cpx* zc = (cpx*)(sm + XS_N);              // transform values [32][200], (re, im) pairs
+    float* tab = sm + XS_N + 2 * Z_N;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int t = blockIdx.x;
-    if (t < n_tiles) {
-        stage_edge_tile<4>(tile_info(audio, d_off, d_len, tile_utt, tile_f0, t), sm, tid, MEL_THREADS);
-    }
+    for (int i = tid; i < TAB_N; i += MEL_THREADS) tab[i] = tables[i];
+    // this wave's filterbank fragments (B operand of the phase-4 products) stay in registers for the whole kernel
+    float bf[SET_STEPS];
+#pragma unroll
+    for (int i = 0; i < SET_STEPS; ++i) bf[i] = fb_frags[((wave >> 1) * SET_STEPS + i) * 64 + lane];
 
-    if (wave < NTILES) {
-        // ================= transform waves =================
-        const int li = lane & 15, lg = lane >> 4;
-        float tw[4][KSTEPS];
+    // Tile order.  Workgroups b, b + 8, b + 16, ... run on one XCD (round-robin dispatch) and share its L2.  Each XCD takes
+    // one contiguous eighth of the tiles and deals it tile by tile to its workgroups, so that at any time an XCD works
+    // on neighbouring tiles: consecutive tiles of an utterance share 240 samples of input, and their 128-byte pieces of
+    // the 128 output rows meet in one L2 and leave it as long runs instead of isolated pieces 12 KB apart.
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, stride = ((int)gridDim.x - xcd + 7) >> 3;   // workgroups of this XCD
+    const int per = (n_tiles + 7) >> 3;
+    const int t_end = gridDim.x >= 8 ? min(n_tiles, (xcd + 1) * per) : n_tiles;
+    float sv[NLOAD];
+    int t = gridDim.x >= 8 ? xcd * per + local : (int)blockIdx.x;
+    const int t_step = gridDim.x >= 8 ? stride : (int)gridDim.x;
+    if (t < t_end) {
+        fetch_samples(tile_info(audio, d_off, d_len, tile_utt, tile_f0, t), sv, tid);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
+        for (int i = 0; i < NLOAD; ++i) xs[tid + i * MEL_THREADS] = sv[i];
+    }
+    for (; t < t_end; t += t_step) {
+        const TileInfo cur = tile_info(audio, d_off, d_len, tile_utt, tile_f0, t);
+        const int tn = t + t_step;
+        __syncthreads();   // this tile's samples (and, the first time, the tables) are in LDS
+
+        // the next tile's samples travel through registers while this tile is transformed
+        if (tn < t_end) fetch_samples(tile_info(audio, d_off, d_len, tile_utt, tile_f0, tn), sv, tid);
+
+        // ---- phase 1: window, radix-8 butterflies over n1 (z index m = 25 n1 + n2), twiddles W200^(n2 k1) ----
+        for (int u = tid; u < TF * 25; u += MEL_THREADS) {
+            const int f = u / 25, n2 = u - 25 * f;
+            const cpx* xf = (const cpx*)(xs + f * MEL_HOP) + n2;
+            const cpx* hw = (const cpx*)(tab + TAB_HANN) + n2;
+            cpx z[8];
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) tw[pr][s] = twid[((s * 4 + pr) * NTILES + wave) * 64 + lane];
-        const int k = 16 * wave + li;
-        int buf = 0;
-        for (; t < n_tiles; t += gridDim.x) {
-            __syncthreads();  // this tile's samples are staged; the power buffer written below has been consumed
-            float* pw = pwr + buf * POW_N;
-            // Tap e of frame fr sits at fr * 160 + e + frame_skew(fr + e / 160); e / 160 is fixed per step except at step 10.
-            // Forward taps (e, e + 1) are read upwards from pa*, mirrored taps (399 - e, 400 - e) from pb*, whose origin
-            // is the lowest mirrored tap.  The next 16 frames lie 16 * 160 + frame_skew(16) floats further on.
-            constexpr int MIRROR0 = MEL_NFFT - 1 - 8 * (KSTEPS - 1);
-            constexpr int ROWTILE = 16 * MEL_HOP + 32;
-            const int row0 = buf * SREG + li * MEL_HOP;
-            int qa0 = row0 + frame_skew(li) + 2 * lg;                 // taps e < 160
-            int qa1 = row0 + frame_skew(li + 1) + 2 * lg;             // taps e >= 160
-            int qb2 = row0 + frame_skew(li + 2) + MIRROR0 - 2 * lg;   // mirrored taps 400 - e >= 320
-            int qb1 = row0 + frame_skew(li + 1) + MIRROR0 - 2 * lg;   // mirrored taps 400 - e < 320
-            int qbe = lg == 0 ? qb2 : qb1;                            // step 10: e = 80 mirrors to 320, e > 80 below it
-            // opaque to the compiler: keeps every read an immediate offset from these five registers
-            asm volatile("" : "+v"(qa0), "+v"(qa1), "+v"(qb2), "+v"(qb1), "+v"(qbe));
-            // operands of step g + 2 are read from LDS before the MFMAs of step g are issued (g runs over all row tiles)
-            f32x2 fw[3], mr[3];  // (x[e], x[e+1]) and (x[399-e], x[400-e])
-            auto fetch = [&](int g) {
-                const int st = g % KSTEPS;
-                if (st == 0 && g > 0) {
-                    qa0 += ROWTILE, qa1 += ROWTILE, qb2 += ROWTILE, qb1 += ROWTILE, qbe += ROWTILE;
-                    asm volatile("" : "+v"(qa0), "+v"(qa1), "+v"(qb2), "+v"(qb1), "+v"(qbe));
-                }
-                const int pa = st < 20 ? qa0 : qa1;
-                const int pb = st < 10 ? qb2 : (st == 10 ? qbe : qb1);
-                const int pd = st < 10 ? qb2 : qb1;
-                fw[g % 3] = (f32x2){sm[pa + 8 * st], sm[pa + 8 * st + 1]};
-                mr[g % 3] = (f32x2){sm[pd + 8 * (KSTEPS - 1 - st)], sm[pb + 8 * (KSTEPS - 1 - st) + 1]};
-            };
-            // power spectrum |X[k]|^2 (AudioPreprocessing.swift:207): bins k and 200-k from the same four sums
-            auto power = [&](const f32x4 (&acc)[4], int mt) {
-                if (k <= 100) {
+            for (int n1 = 0; n1 < 8; ++n1) z[n1] = xf[25 * n1] * hw[25 * n1];
+            const cpx a0 = z[0] + z[4], a1 = z[0] - z[4], a2 = z[2] + z[6], a3 = z[2] - z[6];
+            const cpx b0 = z[1] + z[5], b1 = z[1] - z[5], b2 = z[3] + z[7], b3 = z[3] - z[7];
+            const cpx c0 = a0 + a2, c2 = a0 - a2, c1 = add_mi(a1, a3), c3 = add_pi(a1, a3);
+            const cpx e0 = b0 + b2, e2 = b0 - b2, e1 = add_mi(b1, b3), e3 = add_pi(b1, b3);
+            const cpx R = splat(0.70710678118654752440f);
+            const cpx w1 = R * add_mi(e1, e1);    // e1 * (1 - i) / sqrt 2
+            const cpx w3 = R * add_pi(e3, e3);    // -e3 * (-1 - i) / sqrt 2
+            cpx y[8];
+            y[0] = c0 + e0; y[4] = c0 - e0;
+            y[1] = c1 + w1; y[5] = c1 - w1;
+            y[2] = add_mi(c2, e2); y[6] = add_pi(c2, e2);
+            y[3] = c3 - w3; y[7] = c3 + w3;
+            const cpx* tw = (const cpx*)(tab + TAB_TW) + n2;    // [k1][n2] (cos, -sin): consecutive lanes read consecutive pairs
+            cpx* yo = zc + f * ZS + n2;
+            yo[0] = y[0];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * mt + 4 * lg + r;
-                        const float ce = acc[0][r], co = acc[1][r], se = acc[2][r], so = acc[3][r];
-                        const float re = ce + co, im = se + so;
-                        pw[row * POW_STRIDE + k] = re * re + im * im;
-                        if (k < 100) {
-                            const float re2 = ce - co, im2 = se - so;
-                            pw[row * POW_STRIDE + 200 - k] = re2 * re2 + im2 * im2;
-                        }
-                    }
-                }
-            };
-            {
-                f32x4 acc[2][4];  // two sets: a row tile's power spectrum is written while the next tile's MFMAs run
-                fetch(0);
-                fetch(1);
-#pragma unroll
-                for (int mt = 0; mt < MTILES; ++mt)
-#pragma unroll
-                for (int st = 0; st < KSTEPS; ++st) {
-                    const int g = mt * KSTEPS + st;
-                    // (x[e] + x[400-e], x[e+1] + x[399-e]) and the differences: one packed instruction each,
-                    // the mirrored pair taken with its halves swapped
-                    f32x2 sum, dif;
-                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(sum) : "v"(fw[g % 3]), "v"(mr[g % 3]));
-                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
-                        : "=v"(dif) : "v"(fw[g % 3]), "v"(mr[g % 3]));
-                    if (g + 2 < MTILES * KSTEPS) fetch(g + 2);
-                    __builtin_amdgcn_sched_barrier(0);  // keeps those reads ahead of this step's arithmetic
-                    // the window is part of the twiddles: even / odd samples, cosine / sine part
-                    const float av[4] = {sum[0], sum[1], dif[0], dif[1]};
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        const f32x4 c = st == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt & 1][pr];
-                        acc[mt & 1][pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pr], tw[pr][st], c, 0, 0, 0);
-                    }
-                    if (st == 2 && mt > 0) power(acc[(mt - 1) & 1], mt - 1);
-                }
-                power(acc[(MTILES - 1) & 1], MTILES - 1);
-            }
-            buf ^= 1;
-        }
-        __syncthreads();  // releases the last power spectrum to the filterbank wave
-    } else {
-        // ================= filterbank / staging wave =================
-        float fbv[FB_REGS];
-#pragma unroll
-        for (int i = 0; i < FB_REGS; ++i) fbv[i] = fb_packed[i * 64 + lane];
-        // Per tile: filters 0-63 of the previous tile, then filters 64-127; the next tile's samples travel through
-        // registers in two halves, each fetched before one filterbank half and written to the other image after it.
-        constexpr int N1 = ((SAMPLES + 63) / 64 + 1) / 2;
-        float sv[N1];
-        MelOut o;
-        const float* pw_row = nullptr;
-        TileInfo cur, next;
-        bool live = false;
-        auto begin_tile = [&](int tile, const float* pw_tile) {
-            cur = tile_info(audio, d_off, d_len, tile_utt, tile_f0, tile);
-            const int frames_total = (int)(cur.n / MEL_HOP) + 1;
-            const int frames_out = min(frames_total - 1, MEL_MAX_FRAMES);
-            const int frame = cur.f0 + lane;
-            const bool in_tile = lane < MEL_TILE_FRAMES;   // lanes beyond the tile do nothing
-            o.out = out + (int64_t)cur.u * MEL_NMELS * t_stride + frame;
-            o.t_stride = t_stride;
-            o.store = in_tile && frame < frames_out;
-            o.vmax = -INFINITY;
-            // running maximum over every frame the reference computes, the dropped last one included (:269-270)
-            live = in_tile && frame < frames_total;
-            pw_row = pw_tile + min(lane, MEL_TILE_FRAMES - 1) * POW_STRIDE;
-        };
-        auto end_tile = [&]() {
-            const float vmax = wave_max(live ? o.vmax : -INFINITY);
-            if (lane == 0 && vmax > -INFINITY) atomicMax(d_max + cur.u, enc_max(vmax));
-        };
-        int buf = 0, prev = -1;
-        for (; t < n_tiles; t += gridDim.x) {
-            __syncthreads();
-            const int tn = t + gridDim.x;
-            float* dst = sm + (buf ^ 1) * SREG;
-            bool interior = false;
-            if (tn < n_tiles) {
-                next = tile_info(audio, d_off, d_len, tile_utt, tile_f0, tn);
-                interior = tile_is_interior(next);
-            }
-            if (interior) fetch_tile<N1, 64, 0>(next, sv, lane);
-            if (prev >= 0) {
-                begin_tile(prev, pwr + (buf ^ 1) * POW_N);
-                mel_rows<0, MEL_NMELS / 2>(pw_row, fbv, o);
-            }
-            if (interior) {
-                write_tile<N1, 64, 0>(sv, dst, lane);
-                fetch_tile<N1, 64, N1>(next, sv, lane);
-            }
-            if (prev >= 0) {
-                mel_rows<MEL_NMELS / 2, MEL_NMELS>(pw_row, fbv, o);
-                end_tile();
-            }
-            if (interior) write_tile<N1, 64, N1>(sv, dst, lane);
-            else if (tn < n_tiles) stage_edge_tile<16>(next, dst, lane, 64);
-            prev = t;
-            buf ^= 1;
+            for (int k1 = 1; k1 < 8; ++k1) yo[25 * k1] = cmul(y[k1], tw[25 * k1]);
         }
         __syncthreads();
-        if (prev >= 0) {
-            begin_tile(prev, pwr + (buf ^ 1) * POW_N);
-            mel_rows<0, MEL_NMELS>(pw_row, fbv, o);
-            end_tile();
+
+        // ---- phase 2: one 25-point transform per (frame, k1): n2 = 5 a + b, k2 = c + 5 d.  Thread tid owns row
+        //      f = tid / 8, k1 = tid % 8: rows lie 25 pairs apart and frames 200, so the 16 lanes an 8-byte LDS access
+        //      serves together touch 16 distinct bank pairs. ----
+        {
+            const bool mine = tid < TF * 8;
+            const int f = (tid >> 3) & (TF - 1), k1 = tid & 7;
+            const cpx* yi = zc + f * ZS + 25 * k1;
+            cpx v[5][5];   // [b][a], then [b][c]
+            if (mine) {
+#pragma unroll
+                for (int b = 0; b < 5; ++b)
+#pragma unroll
+                    for (int a = 0; a < 5; ++a) v[b][a] = yi[5 * a + b];
+            }
+            __syncthreads();   // every row has been read: the values can be overwritten in place
+            if (mine) {
+#pragma unroll
+            for (int b = 0; b < 5; ++b) dft5(v[b][0], v[b][1], v[b][2], v[b][3], v[b][4]);
+#pragma unroll
+            for (int b = 1; b < 5; ++b)
+#pragma unroll
+                for (int c = 1; c < 5; ++c) v[b][c] = tw25(v[b][c], b, c);
+            cpx* zo = zc + f * ZS + k1;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                dft5(v[0][c], v[1][c], v[2][c], v[3][c], v[4][c]);   // over b: entry d holds Z[k1 + 8 (c + 5 d)]
+#pragma unroll
+                for (int d = 0; d < 5; ++d) zo[8 * (c + 5 * d)] = v[d][c];
+            }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: real spectrum from A = Z[k] and B = Z[200 - k]: with E2 = A + conj B and O2 = -i (A - conj B),
+        //      X[k] = (E2 + w O2) / 2 and conj X[200 - k] = (E2 - w O2) / 2, w = exp(-i pi k / 200).  Bin 200 feeds no filter. ----
+        for (int u = tid; u < TF * 101; u += MEL_THREADS) {
+            const int f = u / 101, k = u - 101 * f;
+            const cpx A = zc[f * ZS + k], B = zc[f * ZS + (k == 0 ? 0 : 200 - k)];
+            cpx E2, O2;
+            asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(E2) : "v"(A), "v"(B));                               // (ar + br, ai - bi)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(O2) : "v"(A), "v"(B));  // (ai + bi, br - ar)
+            const cpx T = cmul(O2, ((const cpx*)(tab + TAB_UW))[k]);
+            const cpx X = E2 + T, Y = E2 - T;
+            const cpx X2 = X * X, Y2 = Y * Y;
+            float* pw = xs + f * POW_STRIDE;
+            pw[k] = 0.25f * (X2.x + X2.y);
+            if (k > 0 && k < 100) pw[200 - k] = 0.25f * (Y2.x + Y2.y);
+        }
+        __syncthreads();
+
+        // ---- phase 4: slaney filterbank (banded fp32 MFMA), log10, running maximum, stores.  An accumulator holds, per
+        //      lane, one filter's values for four consecutive frames: one 16-byte store per lane. ----
+        {
+            const int frames_total = (int)(cur.n / MEL_HOP) + 1;
+            const int frames_out = min(frames_total - 1, MEL_MAX_FRAMES);
+            const int n = lane & 15, g = lane >> 4, rt = wave & 1;
+            const int frame0 = cur.f0 + 16 * rt + 4 * g;
+            MelTileOut o;
+            o.out = out + (int64_t)cur.u * MEL_NMELS * t_stride + frame0;
+            o.t_stride = t_stride;
+            o.n_store = min(max(frames_out - frame0, 0), 4);
+            // running maximum over every frame the reference computes, the dropped last one included (:269-270)
+            o.n_max = min(max(frames_total - frame0, 0), 4);
+            o.vec = vec_ok;
+            o.vmax = -INFINITY;
+            const float* pw = xs + (16 * rt + n) * POW_STRIDE + g;   // A operand: row = frame, k = bin
+            if (wave < 2) {
+                mel_col_tile<7, 0>(pw, bf, n, o);
+                mel_col_tile<5, ct_steps(7)>(pw, bf, n, o);
+                mel_col_tile<0, ct_steps(7) + ct_steps(5)>(pw, bf, n, o);
+            } else {
+                mel_col_tile<6, 0>(pw, bf, n, o);
+                mel_col_tile<4, ct_steps(6)>(pw, bf, n, o);
+                mel_col_tile<3, ct_steps(6) + ct_steps(4)>(pw, bf, n, o);
+                mel_col_tile<2, ct_steps(6) + ct_steps(4) + ct_steps(3)>(pw, bf, n, o);
+                mel_col_tile<1, ct_steps(6) + ct_steps(4) + ct_steps(3) + ct_steps(2)>(pw, bf, n, o);
+            }
+            const float vmax = wave_max(o.vmax);
+            if (lane == 0 && vmax > -INFINITY) atomicMax(d_max + cur.u, enc_max(vmax));
+        }
+        __syncthreads();   // the power rows have been consumed: the region takes the next tile's samples
+        if (tn < t_end) {
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) xs[tid + i * MEL_THREADS] = sv[i];
         }
     }
-
 }
 
 __global__ void mel_normalize_kernel(float* __restrict__ out, int t_stride, const int* __restrict__ frames_out,
@@ -413,44 +411,49 @@ std::vector<float> build_filterbank() {
 
 void mel_tables_create(MelTables& t) {
     const double PI = 3.14159265358979323846;
-    std::vector<float> hann(HANN_N, 0.f);
-    // AudioPreprocessing.swift:161-164, evaluated in fp32 like the reference
-    for (int i = 0; i <= 200; ++i) hann[i] = 0.5f * (1.0f - cosf(2.0f * (float)M_PI * (float)i / (float)MEL_NFFT));
-
-    // Folded DFT tables as MFMA B-fragments: lane (g = lane>>4, j = lane&15) of step s, product pr,
-    // bin tile nt holds T_pr[n][k] with k = 16 nt + j and n = 2 (4 s + g) (+1 for the odd products).
-    // Angles are reduced (k n mod 400) and evaluated in double: the mathematically exact twiddles.
-    std::vector<float> tw((size_t)KSTEPS * 4 * NTILES * 64, 0.f);
-    for (int s = 0; s < KSTEPS; ++s)
-        for (int pr = 0; pr < 4; ++pr)
-            for (int nt = 0; nt < NTILES; ++nt)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int g = lane >> 4, j = lane & 15, k = 16 * nt + j;
-                    const int n = 2 * (4 * s + g) + (pr & 1);
-                    float v = 0.f;
-                    const bool cosine = pr < 2;
-                    const bool n_ok = cosine ? n <= 200 : (n >= 1 && n <= 199);
-                    if (k <= 100 && n_ok) {
-                        const double ang = 2.0 * PI * (double)((k * n) % MEL_NFFT) / (double)MEL_NFFT;
-                        double val = cosine ? cos(ang) : sin(ang);
-                        if (cosine && n == 200) val *= 0.5;  // the fold counts the centre tap twice
-                        v = (float)(val * (double)hann[n]);  // the window rides on the twiddle
-                    }
-                    tw[(((size_t)s * 4 + pr) * NTILES + nt) * 64 + lane] = v;
-                }
-    t.twid = upload(tw);
+    std::vector<float> tab(TAB_N, 0.f);
+    // periodic Hann window, all 400 taps evaluated in fp32 like the reference (AudioPreprocessing.swift:161-164)
+    for (int i = 0; i < MEL_NFFT; ++i) tab[TAB_HANN + i] = 0.5f * (1.0f - cosf(2.0f * (float)M_PI * (float)i / (float)MEL_NFFT));
+    // twiddles between the radix-8 and the 25-point stage, W200^(n2 k1), and of the real-spectrum untangling,
+    // exp(-i pi k / 200): angles reduced and evaluated in double, i.e. the mathematically exact values rounded once
+    for (int n2 = 0; n2 < 25; ++n2)
+        for (int k1 = 0; k1 < 8; ++k1) {
+            const double ang = 2.0 * PI * (double)((n2 * k1) % 200) / 200.0;
+            tab[TAB_TW + 2 * (k1 * 25 + n2)] = (float)cos(ang);
+            tab[TAB_TW + 2 * (k1 * 25 + n2) + 1] = (float)-sin(ang);
+        }
+    for (int k = 0; k <= 100; ++k) {
+        tab[TAB_UW + 2 * k] = (float)cos(PI * (double)k / 200.0);
+        tab[TAB_UW + 2 * k + 1] = (float)-sin(PI * (double)k / 200.0);
+    }
+    t.twid = upload(tab);
 
     t.host_fb = build_filterbank();
     // The kernel's compile-time filter supports must cover every weight that matters; anything outside them has to be
     // rounding dust of the triangle edges (none with the libm this was built against).
-    std::vector<float> packed((size_t)FB_REGS * 64, 0.f);
     for (int m = 0; m < MEL_NMELS; ++m)
-        for (int b = 0; b < MEL_NBINS; ++b) {
-            const float w = t.host_fb[(size_t)m * MEL_NBINS + b];
-            if (b >= FB_LO[m] && b < FB_LO[m] + FB_W[m]) packed[fb_offset(m) + (b - FB_LO[m])] = w;
-            else Q3_REQUIRE(fabsf(w) < 1e-9f, "mel: the filterbank has a weight outside the kernel's filter supports");
+        for (int b = 0; b < MEL_NBINS; ++b)
+            if (!(b >= FB_LO[m] && b < FB_LO[m] + FB_W[m]))
+                Q3_REQUIRE(fabsf(t.host_fb[(size_t)m * MEL_NBINS + b]) < 1e-9f, "mel: the filterbank has a weight outside the kernel's filter supports");
+    // Weight fragments of the banded products: lane (n = lane & 15, kg = lane >> 4) of step s of column tile ct holds
+    // W[bin = ct_lo + 4 s + kg][filter 16 ct + n], exactly zero outside the filter's support (so whatever the kernel
+    // reads beside a row's bins contributes nothing).
+    std::vector<float> frags((size_t)2 * SET_STEPS * 64, 0.f);
+    for (int set = 0; set < 2; ++set) {
+        int pos = 0;
+        const int n_ct = set == 0 ? 3 : 5;
+        for (int j = 0; j < n_ct; ++j) {
+            const int ct = set == 0 ? SET_A[j] : SET_B[j];
+            for (int st = 0; st < ct_steps(ct); ++st, ++pos)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = 16 * ct + (lane & 15), bin = ct_lo(ct) + 4 * st + (lane >> 4);
+                    if (bin >= FB_LO[m] && bin < FB_LO[m] + FB_W[m])
+                        frags[((size_t)set * SET_STEPS + pos) * 64 + lane] = t.host_fb[(size_t)m * MEL_NBINS + bin];
+                }
         }
-    t.fb_packed = upload(packed);
+        Q3_REQUIRE(pos == SET_STEPS, "mel: filter set size mismatch");
+    }
+    t.fb_packed = upload(frags);
 }
 
 void mel_tables_destroy(MelTables& t) {
@@ -471,9 +474,10 @@ void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, co
     once.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES)); });
     const int cus = device_cus();
     ProfScope ps("mel_kernel", work, s);
-    // one workgroup fits per CU (142 KB of LDS); each loops over its share of the tiles
-    hipLaunchKernelGGL(mel_kernel, dim3(std::min(n_tiles, cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,
-                       d_tile_utt, d_tile_f0, n_tiles, t.twid, t.fb_packed, out, t_stride, d_max);
+    // two workgroups fit per CU (79 KB of LDS each); each loops over its share of the tiles
+    hipLaunchKernelGGL(mel_kernel, dim3(std::min(n_tiles, 2 * cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,
+                       d_tile_utt, d_tile_f0, n_tiles, t.twid, t.fb_packed, out, t_stride, d_max,
+                       (t_stride % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0);   // 16-byte stores need aligned rows
     HIP_CHECK(hipGetLastError());
 }
 
@@ -493,7 +497,7 @@ void launch_mel_normalize(float* out, int B, int t_stride, const int* d_frames_o
 namespace {
 
 constexpr int NOALLOC_MAX_UTT = MEL_NOALLOC_MAX_UTT;
-constexpr int NOALLOC_MAX_TILES = NOALLOC_MAX_UTT * ((MEL_MAX_FRAMES + 1 + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES);   // 63 per 30 s clip
+constexpr int NOALLOC_MAX_TILES = NOALLOC_MAX_UTT * ((MEL_MAX_FRAMES + 1 + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES);   // 94 per 30 s clip
 
 struct NoAllocScratch {
     int64_t off[NOALLOC_MAX_UTT];
@@ -503,9 +507,9 @@ struct NoAllocScratch {
     int tile_utt[NOALLOC_MAX_TILES];
     int tile_f0[NOALLOC_MAX_TILES];
 };
-static_assert(sizeof(NoAllocScratch) <= 160 * 1024, "scratch is meant to stay modest");
+static_assert(sizeof(NoAllocScratch) <= 200 * 1024, "scratch is meant to stay modest");
 
-// 135 KB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the device address is looked up
+// 195 KB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the device address is looked up
 // once per device and every use below goes through that pointer.
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
 
@@ -584,7 +588,7 @@ void mel_noalloc_run(const MelTables& t, const float* audio_dev, const int64_t* 
         bytes += 4.0 * (double)n + 4.0 * MEL_NMELS * (double)mel_frames_out(n);
     }
     Q3_REQUIRE(tiles <= NOALLOC_MAX_TILES, "mel_noalloc: too much audio for the fixed scratch (at most " +
-                                               std::to_string(NOALLOC_MAX_TILES) + " tiles of 48 frames per call)");
+                                               std::to_string(NOALLOC_MAX_TILES) + " tiles of 32 frames per call)");
     Q3_REQUIRE(t_stride >= tmax, "mel_noalloc: t_stride is smaller than the longest utterance's frame count");
     hipLaunchKernelGGL(mel_noalloc_setup_kernel, dim3(1), dim3(256), 0, s, offs, n_utt, sc);
     HIP_CHECK(hipGetLastError());

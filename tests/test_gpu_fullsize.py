@@ -43,10 +43,12 @@ def _full_size_30s(preset, q4, n_clips, monkeypatch):
         assert all(len(t) == steps and all(0 <= x < cfg.vocab for x in t) for t in out.tokens)
         for i in range(64, n_clips):
             assert out.tokens[i] == out.tokens[i % 64], i          # same clip, other slot: same tokens
-        assert len({tuple(t) for t in out.tokens[:64]}) > 1         # and the clips do differ from one another
         # finite logits and the restatement's first-step logits at full depth, one clip
-        tap = m.transcribe_batch(clips[:3], 16000, max_tokens=2, stop_rules=False, tap_steps=2)
+        tap = m.transcribe_batch(clips[:3], 16000, max_tokens=2, stop_rules=False, tap_steps=2, tap_embeds=True)
         assert np.isfinite(tap.taps["logits"]).all()
+        # the clips do differ from one another (with random weights the prompt dominates the argmax, so compare values)
+        emb = tap.taps["audio_embeds"]
+        assert _rel(emb[:390], emb[390:780]) > 1e-2 and not np.array_equal(tap.taps["logits"][0], tap.taps["logits"][1])
         ref = _oracle_first_logits(cfg, ck, clips[0])
         assert _rel(tap.taps["logits"][0, 0], ref) <= LOGIT_RTOL
         srt = np.sort(ref)
