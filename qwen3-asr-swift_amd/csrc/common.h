@@ -45,7 +45,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_buffer(const void* bas
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact (erf) GELU, 0.5 x (1 + erf(x / sqrt 2)) (AudioEncoder.swift:379-384, 127-129: MLX gelu).  erf by the rational
+// approximation of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in erf, measured 4.7e-7 absolute in the GELU over
+// [-8, 8]): two transcendental instructions and a dozen multiply-adds instead of the library erff's ~30 instructions.
+// Every caller rounds the result to bf16 (relative step 4e-3), so the difference from a correctly rounded erf is
+// invisible except as the odd flipped rounding, like any other fp32 evaluation order.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = x * 0.70710678118654752440f, a = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+    const float p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
+    const float er = copysignf(fmaf(-p, e, 1.0f), z);
+    return 0.5f * x * (1.0f + er);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1,5 +1,6 @@
 // Bandwidth-bound glue kernels of the transcription path (gfx950).
 #include "ops.h"
+#include "prof.h"
 #include "rope.h"
 
 namespace {
@@ -512,6 +513,7 @@ void launch_swiglu_reduce(const float* slab, int nslab, int64_t slab_stride, int
 void launch_conv1(const Conv1Params& p, hipStream_t s) {
     if (p.n_chunks <= 0) return;
     Q3_REQUIRE(p.C % 8 == 0 && p.C >= 8 && p.C <= 2048, "conv1: channels must be a multiple of 8 within 2048");
+    ProfScope ps("conv1_kernel", 2.0 * 64 * 50 * (double)p.C * p.n_chunks, s);   // work: bytes written
     hipLaunchKernelGGL(conv1_kernel, dim3(64, p.n_chunks), dim3(256), 0, s, p);
     HIP_CHECK(hipGetLastError());
 }
