@@ -70,6 +70,7 @@ void q3asr_destroy(q3asr_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
+    try { (void)prof_stop(m->stream); } catch (...) {}   // a profile left running must not outlive its streams
     mel_tables_destroy(m->mel);
     m->arena.release();
     for (void* p : m->owned) (void)hipFree(p);
