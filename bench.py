@@ -345,7 +345,10 @@ def main():
             "config": {"workload": label,
                        "clips_per_gpu": n_local, "tokens_per_clip": round(tokens / (n_units_total * args.steps), 1),
                        "decode_row_steps_per_clip": round(row_steps / (n_units_total * args.steps), 1),
-                       "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}"},
+                       "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}",
+                       # > 0: the group decodes as two halves, their attention kernels on this many CUs beside the
+                       # other kernels on the rest (kernel times then overlap: they sum to more than the stage time)
+                       "decode_attention_cus": 0 if args.workload == "mel" else model.decode_attention_cus(min(n_local, args.batch))},
             "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
                          "frac": round(ach / peak, 4), "peak_measured_copy": copy_gbs, "peak_measured_read": read_gbs, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
                          "work_per_launch": per_launch_work, "share_of_device_time": round(top["ms_est"] / sum(p["ms_est"] for p in prof), 3)},

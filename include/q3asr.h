@@ -88,6 +88,10 @@ int q3asr_output_length(const q3asr_model* m, int n_frames);
 /* Device memory the model's per-call workspace currently holds (bytes; it is reused across calls and released by
  * q3asr_destroy).  Counterpart in kind of the reference's resident-memory figure (RuntimeMetrics.swift:9-28). */
 int64_t q3asr_workspace_bytes(q3asr_model* m);
+/* How a group of n_utt utterances is decoded on the model's device: the number of compute units its decode-attention
+ * kernels are confined to while the step's other kernels run beside them on the remaining ones; 0 when the group
+ * decodes on one stream (small groups).  No counterpart in the reference (its decode is one MLX stream). */
+int q3asr_decode_attention_cus(q3asr_model* m, int n_utt);
 
 typedef struct q3asr_request {
     const float* audio;          /* concatenated samples */

@@ -53,7 +53,6 @@ int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
         if (atoi(mb) > 0) m->arena.DEFAULT_BLOCK = (size_t)atoi(mb) << 20;
     try {
         HIP_CHECK(hipStreamCreate(&m->stream));
-        HIP_CHECK(hipStreamCreate(&m->stream2));
         m->zero_page = m->dalloc<bf16_t>(512);
         HIP_CHECK(hipMemset(m->zero_page, 0, 1024));
         mel_tables_create(m->mel);
@@ -75,7 +74,8 @@ void q3asr_destroy(q3asr_model* m) {
     m->arena.release();
     for (void* p : m->owned) (void)hipFree(p);
     for (hipEvent_t e : m->chain_events) (void)hipEventDestroy(e);
-    if (m->stream2) (void)hipStreamDestroy(m->stream2);
+    if (m->stream_att) (void)hipStreamDestroy(m->stream_att);
+    if (m->stream_mm) (void)hipStreamDestroy(m->stream_mm);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -155,6 +155,17 @@ int64_t q3asr_workspace_bytes(q3asr_model* m) {
     return (int64_t)m->arena.footprint();
 }
 
+int q3asr_decode_attention_cus(q3asr_model* m, int n_utt) {
+    if (!m) return -1;
+    try {
+        std::lock_guard<std::mutex> call_lock(m->call_mutex);
+        HIP_CHECK(hipSetDevice(m->device));
+        return model_decode_att_cus(n_utt);
+    } catch (...) {
+        return -1;
+    }
+}
+
 int q3asr_transcribe_tokens(q3asr_model* m, const q3asr_request* req, q3asr_result* res) {
     Q3_API_BEGIN
     Q3_REQUIRE(m, "transcribe: null model");
@@ -167,7 +178,7 @@ int q3asr_profile_start(q3asr_model* m, int stride) {
     Q3_API_BEGIN
     Q3_REQUIRE(m, "profile_start: null model");
     std::lock_guard<std::mutex> call_lock(m->call_mutex);
-    prof_start(m->stream, m->stream2, stride);
+    prof_start(m->stream, stride);
     Q3_API_END
 }
 

@@ -10,8 +10,11 @@
 // exponentiated accumulator is directly the B operand of O^T = V^T P^T (no LDS round trip for P).
 //
 // decode_attn_kernel: one new query per utterance against its KV cache (GQA group shares the
-// K/V stream).  HBM-bound: K rows go straight from global memory into MFMA A fragments, the
-// probabilities are broadcast with v_readlane, V rows are consumed coalesced by the VALU.
+// K/V stream).  HBM-bound: K and V are requested as whole 256-byte rows (a load instruction that takes a
+// 64-byte piece of 16 rows -- the MFMA A-fragment shape -- touches every 128-byte line twice, and a compute unit
+// then sustains 34 instead of 50 GB/s: measured with the bare request patterns, scripts/probe_cu_mask.hip); the
+// K rows become A fragments through a wave-private LDS tile, the probabilities are broadcast with v_readlane,
+// V rows are consumed by the VALU.
 #include "attn.h"
 #include <cstdlib>
 #include "prof.h"
@@ -179,8 +182,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     __shared__ float so[WAVES][GROUP][D];
     __shared__ __attribute__((aligned(16))) bf16_t sq[GROUP][D];  // FUSED: this step's normalised, rotated queries
     __shared__ float snew[2][D];                                  // FUSED: the new key (rotated) and value, bf16-rounded
+    // per wave: one 16-key K tile, rows padded to 272 bytes so that both the row-wise writes and the fragment reads
+    // (16 rows, one 16-byte chunk each) spread over all banks
+    constexpr int KROW = 2 * D + 16;
+    __shared__ __attribute__((aligned(16))) char ktile[WAVES][16 * KROW];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: tile indices and loop branches stay scalar
+    char* const kw = ktile[wave] + (4 * lg) * KROW + 16 * li;        // this lane's chunk of rows 4 lg .. 4 lg + 3
+    const char* const kr = ktile[wave] + li * KROW + 16 * lg;        // fragment ks of key row li: + 64 ks
     // (utterance, kv head) work items, strided over the grid: the launcher may cap the grid so that a fixed
     // number of workgroups per CU stream the cache while another stream's kernels share the CUs
     const int items = p.B * p.kv_heads;
@@ -211,9 +220,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     {                                                                                                          \
         const int kv0_ = (T) * 16;                                                                             \
         /* rows past len-1 are allocated padding (the cache holds 16 spare rows); they are masked below */    \
-        const bf16_t* kp_ = Kb + (int64_t)(kv0_ + li) * D + 8 * lg;                                            \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
-            KF[ks].v = __builtin_nontemporal_load((const bf16x8*)(kp_ + 32 * ks));                            \
+        const bf16_t* kp_ = Kb + (int64_t)(kv0_ + 4 * lg) * D + 8 * li;   /* 16 lanes per row */             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            KF[i].v = __builtin_nontemporal_load((const bf16x8*)(kp_ + i * D));                               \
         const bf16_t* vp_ = Vb + (int64_t)kv0_ * D + 2 * lane;                                                 \
         _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                         \
             VV[k] = __builtin_nontemporal_load((const uint32_t*)(vp_ + k * D));                               \
@@ -222,8 +231,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     {                                                                                                          \
         const int kv0 = (T) * 16;                                                                              \
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                 \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KF[ks].v, qf[ks].v, s, 0, 0, 0);                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) *(uint4*)(kw + i * KROW) = KF[i].u;                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                 \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
+            Frag ka_;                                                                                          \
+            ka_.u = *(const uint4*)(kr + 64 * ks);                                                             \
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka_.v, qf[ks].v, s, 0, 0, 0);                          \
+        }                                                                                                      \
+        __builtin_amdgcn_wave_barrier();   /* the next tile's rows are written after these reads */            \
         float sv[4], tmax = -INFINITY;                                                                         \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
             sv[r] = (!(MASK) || kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;                              \

@@ -36,6 +36,7 @@ struct GemmParams {
     float* part_val = nullptr;      // OUT_ARGMAX: [M][nparts]
     int* part_idx = nullptr;
     int nparts = 0;
+    int cus = 0;                    // compute units the launch stream may use (0: the whole device); sizes persistent grids
     int ksplit = 1;                 // OUT_SLAB: gridDim.z
     int64_t slab_stride = 0;
 };

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 }
 
 // One workgroup per CU, rounded down to a multiple of 8 so that a workgroup's virtual block indices all map to its XCD.
-int persistent_grid() { return std::max(8, device_cus() & ~7); }
+int persistent_grid(int cus) { return std::max(8, (cus > 0 ? std::min(cus, device_cus()) : device_cus()) & ~7); }
 
 template <int OUT, int AMODE = A_PLAIN>
 void launch_o(const GemmParams& p, hipStream_t s) {
@@ -366,7 +366,7 @@ void launch_o(const GemmParams& p, hipStream_t s) {
     static const std::string name = std::string(AMODE == A_PLAIN ? "gemm256_kernel<" : "gemm256_conv_kernel<") + std::to_string(OUT) + ">";
     {
         ProfScope ps(name.c_str(), 2.0 * p.M * p.N * p.K, s);
-        hipLaunchKernelGGL((gemm256_kernel<OUT, AMODE>), dim3(std::min(tiles, persistent_grid()), 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
+        hipLaunchKernelGGL((gemm256_kernel<OUT, AMODE>), dim3(std::min(tiles, persistent_grid(p.cus)), 1, p.ksplit), dim3(512), LDS_BYTES, s, p);
     }
     HIP_CHECK(hipGetLastError());
 }

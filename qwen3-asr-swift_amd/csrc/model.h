@@ -154,7 +154,10 @@ struct q3asr_model {
     };
     std::map<int, DecodePlan> decode_plans;   // measured plans (tuning runs), per row bucket
     std::set<int> plans_reported;             // buckets whose plan the verbose log has shown
-    hipStream_t stream2 = nullptr;           // second decode stream (the two halves of a large group)
+    // Decode of a large group: the attention kernels run on a stream confined to `split_att_cus` compute units and
+    // every other kernel of the step on a stream confined to the remaining ones (created when first needed).
+    hipStream_t stream_att = nullptr, stream_mm = nullptr;
+    int split_att_cus = 0;
     std::vector<hipEvent_t> chain_events;    // ordering events between the two decode streams
 
     template <class T>
@@ -173,3 +176,4 @@ void model_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t*
                   float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space);
 void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* res);
 int model_output_length(const q3asr_config& cfg, int frames);
+int model_decode_att_cus(int n_utt);

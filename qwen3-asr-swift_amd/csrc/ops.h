@@ -116,3 +116,5 @@ float mfma_f32_probe_tflops(float* sink, int waves_per_simd, int iters, hipStrea
 
 // Pseudo-random bf16 values in (-1, 1) for the kernel timing entry points.
 void launch_fill_bf16(bf16_t* p, size_t n, uint32_t seed, hipStream_t s);
+// One empty workgroup: a stream-ordered point that has passed every wait queued before it.
+void launch_noop(hipStream_t s);

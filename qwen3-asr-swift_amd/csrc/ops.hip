@@ -604,6 +604,12 @@ __global__ void fill_bf16_kernel(bf16_t* p, size_t n, uint32_t seed) {
 }
 }  // namespace
 
+__global__ void noop_kernel() {}
+void launch_noop(hipStream_t s) {
+    hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_fill_bf16(bf16_t* p, size_t n, uint32_t seed, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(fill_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, seed);

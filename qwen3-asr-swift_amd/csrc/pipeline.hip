@@ -22,6 +22,8 @@ constexpr int TOK_ASSISTANT = 77091;
 constexpr int ENC_CHUNK_BUDGET = 3840;  // chunks per encoder pass (128 clips of 30 s; conv1's output is 3 MB per chunk;
                                         // measured: 960 -> 673 ms, 3840 -> 590 ms, 7680 -> 581 ms per 1024 clips)
 constexpr int POLL_STEPS = 8;
+constexpr int SPLIT_MIN_ROWS = 1024;    // groups from this size on decode as two halves on disjoint sets of compute units
+constexpr int SPLIT_MERGE_ROWS = 512;   // ... until this few utterances are still running
 
 inline int conv_len(int n) { return (n - 1) / 2 + 1; }
 inline int feat_len(int clen) { return conv_len(conv_len(conv_len(clen))); }
@@ -337,6 +339,7 @@ namespace {
 // accumulate K in the same order with the same MFMA, so the tile never changes a result; the split count and the
 // fused-versus-slab form do (within the bf16 tolerance).  Q3ASR_DECODE_TILE / _SPLIT / _NO_FUSE pin one variant;
 // Q3ASR_DECODE_AUTOTUNE=1 replaces the rule by a measurement of every candidate on layer 0's weights (tuning runs).
+// `cus` > 0: the projections run on a stream confined to that many compute units (0: the whole device).
 int plan_bucket(int rows) {
     int b = 8;
     while (b < rows) b <<= 1;
@@ -348,7 +351,8 @@ void tile_dims(int tile, int& bm, int& bn) {
     bn = tile == 3 ? 256 : (tile == 0 ? 128 : 64);
 }
 
-q3asr_model::DecodePlan decode_plan_rule(const q3asr_model* m, int rows, GemmWFmt wf) {
+q3asr_model::DecodePlan decode_plan_rule(const q3asr_model* m, int rows, GemmWFmt wf, int cus) {
+    const int ncu = cus > 0 ? cus : device_cus();
     const DecLayerW& L = m->dec[0];
     const LinearW* W[4] = {&L.qkv, &L.o, &L.gate_up, &L.down};
     q3asr_model::DecodePlan plan;
@@ -366,18 +370,18 @@ q3asr_model::DecodePlan decode_plan_rule(const q3asr_model* m, int rows, GemmWFm
             if (t == 1 && (R > 512 || g == 2)) continue;   // no SwiGLU epilogue on the 64x64 tile
             int bm, bn;
             tile_dims(t, bm, bn);
-            if ((int64_t)cdiv(R, bm) * cdiv(N, bn) >= (t == 3 ? 192 : 256)) { tile = t; break; }
+            if ((int64_t)cdiv(R, bm) * cdiv(N, bn) >= (t == 3 ? ncu * 3 / 4 : ncu)) { tile = t; break; }
         }
         if (tile < 0) {
             tile = R <= 64 && g != 2 ? 1 : 2;
             int bm, bn;
             tile_dims(tile, bm, bn);
             const int64_t wgs = (int64_t)cdiv(R, bm) * cdiv(N, bn);
-            while (ks < 8 && wgs * ks < 256 && ktiles / (ks * 2) >= 4) ks *= 2;
+            while (ks < 8 && wgs * ks < ncu && ktiles / (ks * 2) >= 4) ks *= 2;
         }
         bool want_fused = ks == 1;
         for (const DecodePlanEntry& e : DECODE_PLAN_TABLE)
-            if (e.N == N && e.K == K && e.wfmt == (int)wf && e.bucket == R) {
+            if (e.N == N && e.K == K && e.wfmt == (int)wf && e.bucket == R && e.cus == cus) {
                 tile = e.tile;
                 ks = std::max(1, e.split);
                 want_fused = e.split == 0;
@@ -397,7 +401,7 @@ q3asr_model::DecodePlan decode_plan_rule(const q3asr_model* m, int rows, GemmWFm
 // Times every candidate of the four projections at `b` rows.  Launch i of a candidate uses layer i's weights, so the
 // weights come from HBM as they do in a decode step (28 layers of the 1.7B model are 3.4 GB, far beyond the caches),
 // while the activations stay hot as the previous kernel's output would be.
-q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
+q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf, int cus, hipStream_t s) {
     q3asr_model* m = c.m;
     const int layers = (int)m->dec.size();
     auto weight = [&](int l, int g) -> const LinearW& {
@@ -412,7 +416,7 @@ q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
     const auto mark = m->arena.mark();
     bf16_t* A = c.get<bf16_t>((size_t)b * max_k);
     float* slab = c.get<float>((size_t)8 * b * max_n);
-    launch_fill_bf16(A, (size_t)b * max_k, 0x51u, c.s);
+    launch_fill_bf16(A, (size_t)b * max_k, 0x51u, s);
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -435,15 +439,15 @@ q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
                 const GemmOut out = ks == 0 ? fused_out[g] : OUT_SLAB;
                 float ms = 1e30f;
                 for (int pass = 0; pass < 3; ++pass) {   // pass 0 warms up; the faster of the other two counts
-                    if (pass) HIP_CHECK(hipEventRecord(e0, c.s));
+                    if (pass) HIP_CHECK(hipEventRecord(e0, s));
                     for (int l = 0; l < layers; ++l) {
                         GemmParams p = gp(c, A, K, weight(l, g), b);
                         p.out = slab; p.ldo = g == 2 && ks == 0 ? N / 2 : N;
-                        p.ksplit = std::max(ks, 1); p.slab_stride = (int64_t)b * N;
-                        launch_gemm(p, A_PLAIN, out, wf, tile, c.s);
+                        p.ksplit = std::max(ks, 1); p.slab_stride = (int64_t)b * N; p.cus = cus;
+                        launch_gemm(p, A_PLAIN, out, wf, tile, s);
                     }
                     if (pass) {
-                        HIP_CHECK(hipEventRecord(e1, c.s));
+                        HIP_CHECK(hipEventRecord(e1, s));
                         HIP_CHECK(hipEventSynchronize(e1));
                         float t = 0;
                         HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
@@ -454,39 +458,66 @@ q3asr_model::DecodePlan decode_plan_measured(Ctx& c, int b, GemmWFmt wf) {
                 const double extra_us = ks == 0 ? 0.0 : ks * b * (double)N * 4.0 / 3.0e6 + (g == 2 ? 4.0 : 0.0);
                 const double us = ms * 1000.0 / layers + extra_us;
                 if (getenv("Q3ASR_VERBOSE") && atoi(getenv("Q3ASR_VERBOSE")) > 1)
-                    fprintf(stderr, "q3asr: rows %d proj %d tile %d split %d: %.1f us (+%.1f us for its partial sums)\n", b, g, tile, ks,
+                    fprintf(stderr, "q3asr: cus %d rows %d proj %d tile %d split %d: %.1f us (+%.1f us for its partial sums)\n", cus, b, g, tile, ks,
                             ms * 1000.0 / layers, extra_us);
                 if (us < best) { best = us; plan.tile[g] = tile; plan.ks[g] = std::max(ks, 1); plan.fused[g] = ks == 0; }
             }
         }
     }
+    HIP_CHECK(hipStreamSynchronize(s));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     m->arena.restore(mark);
     return plan;
 }
 
-q3asr_model::DecodePlan decode_plan(Ctx& c, int rows, GemmWFmt wf) {
+q3asr_model::DecodePlan decode_plan(Ctx& c, int rows, GemmWFmt wf, int cus, hipStream_t s) {
     q3asr_model* m = c.m;
-    const int bucket = plan_bucket(rows);
+    const int bucket = plan_bucket(rows), key = bucket + (cus << 20);
     const char* env_auto = getenv("Q3ASR_DECODE_AUTOTUNE");
     const bool measured = env_auto && atoi(env_auto) != 0;
     q3asr_model::DecodePlan plan;
     bool fresh = true;
     if (measured) {   // a measurement is kept per bucket; the rule is cheap and follows the pinning variables of each call
-        const auto hit = m->decode_plans.find(bucket);
+        const auto hit = m->decode_plans.find(key);
         fresh = hit == m->decode_plans.end();
-        plan = fresh ? decode_plan_measured(c, rows, wf) : hit->second;
-        m->decode_plans[bucket] = plan;
+        plan = fresh ? decode_plan_measured(c, rows, wf, cus, s) : hit->second;
+        m->decode_plans[key] = plan;
     } else {
-        plan = decode_plan_rule(m, rows, wf);
-        fresh = m->plans_reported.insert(bucket).second;
+        plan = decode_plan_rule(m, rows, wf, cus);
+        fresh = m->plans_reported.insert(key).second;
     }
     if (fresh && getenv("Q3ASR_VERBOSE"))
-        fprintf(stderr, "q3asr: decode plan for up to %d rows%s (tile/split, split 0 = fused epilogue): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n",
-                bucket, measured ? " (measured)" : "", plan.tile[0], plan.fused[0] ? 0 : plan.ks[0], plan.tile[1], plan.fused[1] ? 0 : plan.ks[1],
-                plan.tile[2], plan.fused[2] ? 0 : plan.ks[2], plan.tile[3], plan.fused[3] ? 0 : plan.ks[3]);
+        fprintf(stderr, "q3asr: decode plan for up to %d rows on %d CUs%s (tile/split, split 0 = fused epilogue): qkv %d/%d, o %d/%d, gate_up %d/%d, down %d/%d\n",
+                bucket, cus > 0 ? cus : device_cus(), measured ? " (measured)" : "", plan.tile[0], plan.fused[0] ? 0 : plan.ks[0], plan.tile[1],
+                plan.fused[1] ? 0 : plan.ks[1], plan.tile[2], plan.fused[2] ? 0 : plan.ks[2], plan.tile[3], plan.fused[3] ? 0 : plan.ks[3]);
     return plan;
+}
+
+// Compute units the decode attention of a group of `b` utterances is confined to (0: one stream, the whole device for
+// every kernel).  Q3ASR_DECODE_ATT_CUS pins the share (tests, tuning).
+int decode_att_cus(int b) {
+    const int cus_all = device_cus();
+    const char* env_att = getenv("Q3ASR_DECODE_ATT_CUS");
+    int att_cus = (env_att ? atoi(env_att) : (b >= SPLIT_MIN_ROWS ? cus_all * 5 / 8 : 0)) & ~7;
+    if (b < 2 || cus_all % 8 != 0 || att_cus < 8 || cus_all - att_cus < 8) att_cus = 0;
+    return att_cus;
+}
+
+// Streams confined to complementary sets of compute units: mask bit i selects CU i / 8 of XCD i % 8, so the first
+// `att_cus` bits (a multiple of 8) take the same number of CUs from every XCD (a mask that leaves an XCD without a
+// CU is not accepted by the runtime).
+void ensure_split_streams(q3asr_model* m, int att_cus) {
+    if (m->stream_att && m->split_att_cus == att_cus) return;
+    if (m->stream_att) { HIP_CHECK(hipStreamDestroy(m->stream_att)); m->stream_att = nullptr; }
+    if (m->stream_mm) { HIP_CHECK(hipStreamDestroy(m->stream_mm)); m->stream_mm = nullptr; }
+    const int cus = device_cus(), words = (cus + 31) / 32;
+    Q3_REQUIRE(cus % 8 == 0 && att_cus % 8 == 0 && att_cus >= 8 && cus - att_cus >= 8, "decode: bad compute-unit split");
+    std::vector<uint32_t> ma(words, 0), mb(words, 0);
+    for (int i = 0; i < cus; ++i) (i < att_cus ? ma : mb)[i >> 5] |= 1u << (i & 31);
+    HIP_CHECK(hipExtStreamCreateWithCUMask(&m->stream_att, (uint32_t)words, ma.data()));
+    HIP_CHECK(hipExtStreamCreateWithCUMask(&m->stream_mm, (uint32_t)words, mb.data()));
+    m->split_att_cus = att_cus;
 }
 
 struct Events {
@@ -636,10 +667,12 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
 
     // LM head on `rows` normalised rows -> st_argmax (and optional logits tap)
     // (utterances r0 .. r0 + rows - 1 of the group, on stream s)
+    int cur_cus = 0;   // compute units of the stream the decode projections are issued on (0: the whole device)
     auto lm_head = [&](const bf16_t* x, int r0, int rows, int step, hipStream_t s) {
         const bool tap = logits && step < req->tap_steps;
         const int head_tile = head_tile_for(rows);
         GemmParams p = gp(c, x, H, m->embed, rows);
+        p.cus = cur_cus;
         if (tap) {
             float* lg = logits + (size_t)r0 * cfg.vocab;
             p.out = lg; p.ldo = cfg.vocab;
@@ -722,38 +755,43 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
 
     // ---- greedy decode (Qwen3ASR.swift:567-632) ----
     {
-        // The step's attention streams the KV cache (HBM-bound) while its projections are MFMA-bound,
-        // so a large group is decoded as two halves on two streams, chained by events so that the
-        // attention kernels of the halves alternate and each half's projections run beside the other
-        // half's attention.  Opt-in (Q3ASR_DECODE_STREAMS=2): measured +3 % at 1024 clips, nothing at 512, and
-        // the co-running kernels stretch each other, which blurs per-kernel timings.
-        const char* env_streams = getenv("Q3ASR_DECODE_STREAMS");
-        const int n_half = env_streams && atoi(env_streams) >= 2 && b >= 2 ? 2 : 1;
+        // The step's attention streams the KV cache: it is HBM-bound, and one compute unit sustains ~55 GB/s of that
+        // stream, so 160 of the 256 CUs already draw what the memory gives (6.8 against 7.0 TB/s in a bare read loop).
+        // The step's projections are MFMA-bound.  A large group is therefore decoded as two halves: the attention
+        // kernels of both run on a stream confined to `att_cus` CUs, everything else on a stream confined to the
+        // remaining ones, chained by events so that one half's attention runs beside the other half's projections
+        // (plain concurrent streams do not overlap them: each kernel fills every CU's registers on its own).
+        // The share is a fixed function of the group size (decode_att_cus): measured on the 1.7B model at 2048 clips,
+        // 160 + 96 CUs decode 9 % faster than one stream, 128 + 128 3 % faster, 144 + 112 slower (the 256-wide
+        // projection tiles fill 96 CUs in whole rounds); groups below 1024 utterances are faster on one stream.
+        const int att_cus = decode_att_cus(b);
+        const int mm_cus = att_cus ? device_cus() - att_cus : 0;
+        int n_half = att_cus ? 2 : 1;
+        const bool was_split = n_half == 2;
+        if (was_split) ensure_split_streams(m, att_cus);
+        bool chain = was_split;   // attention and the other kernels are on different streams
         // The reference computes nothing for a clip once it has stopped (:571-574).  Here a stopped utterance is skipped by
         // the attention kernel at once (its done flag) and leaves the step's rows at the next poll: the step kernel
         // writes the list of utterances still running, and switching the row -> utterance map to that list shrinks
         // every per-row kernel of the following steps (nothing is moved: the cache and all per-utterance state are
-        // indexed by utterance).  Off for the two-stream mode and for the logits tap (whose host copies are per row).
+        // indexed by utterance).  Off for the logits tap (whose host copies are per row).
         const char* env_retire = getenv("Q3ASR_RETIRE");
         const bool skip_done = !(env_retire && atoi(env_retire) == 0);   // Q3ASR_RETIRE=0: every row is computed until the group ends
-        const bool retire = n_half == 1 && !logits && skip_done;
-        // With two streams the attention grid is capped (workgroups loop over their items) so that the
-        // other half's projection kernels always find free registers and LDS on every CU.
-        const char* env_blocks = getenv("Q3ASR_ATTN_BLOCKS");
-        const int attn_blocks = env_blocks ? atoi(env_blocks) : 0;
+        const bool retire = !logits && skip_done;
         const char* env_gemv = getenv("Q3ASR_DECODE_GEMV");
         const char* env_auto = getenv("Q3ASR_DECODE_AUTOTUNE");
         const bool autotune = env_auto && atoi(env_auto) != 0;
         struct Half {
             int r0, n;      // first row and row count at the start (= utterances of the half)
-            int rows;       // rows still decoded
+            int rows;       // rows still decoded (0: every utterance of the half has stopped)
             int cur;        // which of st_map holds the half's row -> utterance list
-            hipStream_t s;
+            hipStream_t s, sa;   // stream of the attention kernels (sa) and of everything else (s)
             float* hid; bf16_t *xn, *qkvb, *qd, *att, *act, *x_last; float* slab;
             int* active_dev;
             long long* keys;
             q3asr_model::DecodePlan plan;
             bool gemv;  // a handful of rows: projections as fused GEMV kernels (gemv.hip), no partial-sum slabs
+            bool pre_issued;   // the next step's embedding, input norm and q/k/v projection are already enqueued
         } hv[2];
         auto gemv_ok = [&](int rows) {
             return !(env_gemv && atoi(env_gemv) == 0) && gemv_supports(rows, QKV, H, GEMV_NORM_BF16, wf) &&
@@ -765,7 +803,8 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         auto set_rows = [&](Half& x, int rows) {
             x.rows = rows;
             x.gemv = gemv_ok(rows);
-            x.plan = x.gemv ? q3asr_model::DecodePlan{} : decode_plan(c, rows, wf);
+            x.plan = x.gemv ? q3asr_model::DecodePlan{} : decode_plan(c, rows, wf, cur_cus, x.s);
+            x.pre_issued = false;
         };
         auto slab_need = [&](const q3asr_model::DecodePlan& pl, int rows) {
             size_t e = (size_t)pl.ks[0] * rows * QKV;
@@ -773,12 +812,14 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             e = std::max(e, (size_t)pl.ks[2] * rows * 2 * cfg.inter);
             return std::max(e, (size_t)pl.ks[3] * rows * H);
         };
+        cur_cus = mm_cus;
         for (int h = 0; h < n_half; ++h) {
             Half& x = hv[h];
             x.r0 = h ? hv[0].n : 0;
             x.n = n_half == 1 ? b : (h ? b - hv[0].n : (b + 1) / 2);
             x.cur = 0;
-            x.s = h ? m->stream2 : c.s;
+            x.s = was_split ? m->stream_mm : c.s;
+            x.sa = chain ? m->stream_att : c.s;
             x.hid = c.get<float>((size_t)x.n * H);
             x.xn = c.get<bf16_t>((size_t)x.n * H);
             x.qd = c.get<bf16_t>((size_t)x.n * nh * hd);
@@ -789,25 +830,30 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             x.active_dev = st_active + h;
             x.keys = st_keys + (size_t)h * (max_tokens + 2);
             // the slab must hold the partial sums of every plan the half can pass through while it shrinks
+            // (on its share of the CUs and, once the halves have been merged, on the whole device)
             size_t slab_elems = 256;
             if (autotune) {
                 slab_elems = (size_t)8 * x.n * std::max(std::max(QKV, 2 * cfg.inter), H);
             } else {
                 for (int top = 8;; top <<= 1) {
                     const int r = std::min(top, x.n);
-                    if (!gemv_ok(r)) slab_elems = std::max(slab_elems, slab_need(decode_plan_rule(m, r, wf), r));
+                    if (!gemv_ok(r)) {
+                        slab_elems = std::max(slab_elems, slab_need(decode_plan_rule(m, r, wf, mm_cus), r));
+                        if (was_split) slab_elems = std::max(slab_elems, slab_need(decode_plan_rule(m, r, wf, 0), r));
+                    }
                     if (top >= x.n) break;
                 }
             }
             x.slab = c.get<float>(slab_elems);
-            set_rows(x, x.n);
         }
+        int* st_tmp = was_split ? c.get<int>(b) : nullptr;   // staging of the merged row -> utterance list
         // One projection: split-K partial sums into the slab, or (fused plan) unsplit with the consumer's
         // work in the epilogue, writing `fused_dst` with row stride `fused_ld`.  Returns the number of slabs
         // the consumer still has to reduce (0 when fused).
         auto proj = [&](const Half& x, const bf16_t* A, int64_t lda, const LinearW& W, int which, GemmOut fused_kind, void* fused_dst,
                         int64_t fused_ld) {
             GemmParams p = gp(c, A, lda, W, x.rows);
+            p.cus = cur_cus;
             if (x.plan.fused[which]) {
                 p.out = fused_dst; p.ldo = fused_ld;
                 launch_gemm(p, A_PLAIN, fused_kind, wf, x.plan.tile[which], x.s);
@@ -817,24 +863,36 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             launch_gemm(p, A_PLAIN, OUT_SLAB, wf, x.plan.tile[which], x.s);
             return x.plan.ks[which];
         };
-        // per-layer "attention issued" events of each half
-        if ((int)m->chain_events.size() < 2 * cfg.layers + 2) {
+        // per half and layer: "q/k/v rows ready" and "attention done" events between the two streams
+        if ((int)m->chain_events.size() < 4 * cfg.layers + 2) {
             const size_t old = m->chain_events.size();
-            m->chain_events.resize(2 * cfg.layers + 2);
+            m->chain_events.resize(4 * cfg.layers + 2);
             for (size_t i = old; i < m->chain_events.size(); ++i) HIP_CHECK(hipEventCreateWithFlags(&m->chain_events[i], hipEventDisableTiming));
         }
-        hipEvent_t* ev_attn[2] = {m->chain_events.data(), m->chain_events.data() + cfg.layers};
-        hipEvent_t ev_fork = m->chain_events[2 * cfg.layers], ev_join = m->chain_events[2 * cfg.layers + 1];
+        hipEvent_t* ev_pre[2] = {m->chain_events.data(), m->chain_events.data() + cfg.layers};
+        hipEvent_t* ev_attn[2] = {m->chain_events.data() + 2 * cfg.layers, m->chain_events.data() + 3 * cfg.layers};
+        hipEvent_t ev_fork = m->chain_events[4 * cfg.layers], ev_join = m->chain_events[4 * cfg.layers + 1];
         int active = b;
         HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
         HIP_CHECK(hipStreamSynchronize(c.s));
-        if (retire && active > 0 && active < b) {   // utterances that stopped on the prefill's token
-            hv[0].cur = 1;
-            set_rows(hv[0], active);
-        }
-        if (n_half == 2) {  // the second stream starts after everything queued so far
-            HIP_CHECK(hipEventRecord(ev_fork, c.s));
-            HIP_CHECK(hipStreamWaitEvent(m->stream2, ev_fork, 0));
+        if (was_split) {
+            // the prefill's step kernel ran over the whole group: the halves start from their slices of the identity
+            // list and drop the utterances that stopped on the prefill's token at the first poll (their done flags
+            // already keep them out of the attention)
+            for (int h = 0; h < 2; ++h) set_rows(hv[h], hv[h].n);
+            HIP_CHECK(hipEventRecord(ev_fork, c.s));   // both streams start after everything queued so far
+            HIP_CHECK(hipStreamWaitEvent(m->stream_att, ev_fork, 0));
+            HIP_CHECK(hipStreamWaitEvent(m->stream_mm, ev_fork, 0));
+            if (prof_active(c.s)) {
+                prof_attach(c.s, m->stream_att);
+                prof_attach(c.s, m->stream_mm);
+            }
+        } else {
+            set_rows(hv[0], hv[0].n);
+            if (retire && active > 0 && active < b) {   // utterances that stopped on the prefill's token
+                hv[0].cur = 1;
+                set_rows(hv[0], active);
+            }
         }
         int pend_down[2] = {0, 0};  // slabs the last down-projection of each half left to reduce
         int qkv_slabs[2] = {0, 0};  // slabs of the current q/k/v projection (0: bf16 rows in qkvb)
@@ -842,132 +900,178 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         const bool fuse_rope = !(env_fuse && atoi(env_fuse) == 0) && nh / nkv <= 4 && (nh / nkv == 1 || nh / nkv == 2 || nh / nkv == 4);
         // profiling: the attention's algorithmic bytes are only known on the device (which utterances still run), so its
         // launches are recorded without work and the exact figure is added after the loop from the step kernel's key counts
-        const bool exact_work = n_half == 1;
-        std::vector<int> attn_launched(max_tokens + 2, 0), attn_timed(max_tokens + 2, 0);
-        // enqueues one decode step (every per-step quantity is read from device arrays, so the launches of all
-        // steps between two polls are identical; `it` only feeds the profiler's byte count and the logits tap)
-        auto issue_step = [&](int it) {
-            for (int h = 0; h < n_half; ++h)
-                launch_embed_tokens(st_next, st_map[hv[h].cur] + hv[h].r0, hv[h].rows, H, qemb ? nullptr : (const bf16_t*)m->embed.w,
-                                    qemb ? (const uint32_t*)m->embed.w : nullptr, m->embed.scales, m->embed.biases, cfg.group_size,
-                                    hv[h].hid, hv[h].s);
-            for (int l = 0; l < cfg.layers; ++l) {
-                const DecLayerW& L = m->dec[l];
-                bf16_t* kl = kc + l * layer_stride;
-                bf16_t* vl = vc + l * layer_stride;
-                for (int h = 0; h < n_half; ++h) {
-                    const Half& x = hv[h];
-                    const int* map = st_map[x.cur] + x.r0;
-                    if (x.gemv) {  // input norm inside the q/k/v kernel
-                        GemvParams g;
-                        g.w = L.qkv.w; g.scales = L.qkv.scales; g.biases = L.qkv.biases; g.qgroup = cfg.group_size; g.N = QKV; g.K = H; g.M = x.rows; g.hid = x.hid; g.norm_w = L.in_norm; g.eps = cfg.rms_eps;
-                        g.out = x.qkvb; g.ldo = QKV;
-                        launch_gemv(g, GEMV_NORM_BF16, x.s);
-                        qkv_slabs[h] = 0;
-                    } else {
-                        // residual += previous layer's down-projection partials (if it left any), then input norm
-                        launch_rmsnorm(x.hid, L.in_norm, x.xn, x.rows, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.rows * H, x.s);
-                        qkv_slabs[h] = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
-                    }
-                    if (!fuse_rope) {
-                        const int ns = qkv_slabs[h];
-                        RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.rows * QKV, x.qd, (int64_t)nh * hd, x.rows,
-                                      nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
-                                      m->rope_max_pos, map, nullptr, st_len, kl, vl, utt_stride, head_stride};
-                        launch_rope(rp, x.s);
-                    }
-                }
-                for (int h = 0; h < n_half; ++h) {
-                    const Half& x = hv[h];
-                    if (n_half == 2) {
-                        // half 0 follows half 1's attention of the previous layer, half 1 follows half 0's of this layer
-                        const int dep_l = h ? l : (l ? l - 1 : cfg.layers - 1);
-                        if (h || l || it > 1) HIP_CHECK(hipStreamWaitEvent(x.s, ev_attn[h ^ 1][dep_l], 0));
-                    }
-                    double kv_bytes = 0;
-                    if (prof_active(x.s)) {
-                        if (exact_work) {
-                            attn_launched[it] += 1;
-                            attn_timed[it] += prof_next_timed("decode_attn_kernel", x.s) ? 1 : 0;
-                        } else {   // K and V rows visible this step, counted as if no utterance had stopped yet
-                            for (int i = 0; i < x.n; ++i) kv_bytes += 2.0 * 2.0 * nkv * hd * (double)(utt_rows[x.r0 + i] + it);
-                        }
-                    }
-                    DecodeAttnParams dp{x.qd, (int64_t)nh * hd, kl, vl, utt_stride, head_stride,
-                                        st_len, fuse_rope ? 0 : 1, x.att, (int64_t)nh * hd, x.rows, nkv, nh / nkv, scale};
-                    dp.max_blocks = attn_blocks;
-                    dp.slot = st_map[x.cur] + x.r0;
-                    dp.done = skip_done ? st_done : nullptr;
-                    if (fuse_rope) {  // q/k norm, RoPE and the cache append happen inside the attention kernel
-                        const int ns = qkv_slabs[h];
-                        dp.rope = DecodeRopeIn{ns ? nullptr : x.qkvb, ns ? x.slab : nullptr, ns, (int64_t)x.rows * QKV, QKV, L.q_norm, L.k_norm,
-                                               cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos};
-                    }
-                    launch_decode_attn(dp, hd, x.s, kv_bytes);
-                    if (n_half == 2) HIP_CHECK(hipEventRecord(ev_attn[h][l], x.s));
-                }
-                for (int h = 0; h < n_half; ++h) {
-                    const Half& x = hv[h];
-                    if (x.gemv) {  // o (+= residual), post norm + gate/up + SwiGLU, down (+= residual)
-                        GemvParams g;
-                        g.M = x.rows; g.eps = cfg.rms_eps; g.qgroup = cfg.group_size;
-                        g.w = L.o.w; g.scales = L.o.scales; g.biases = L.o.biases; g.N = H; g.K = nh * hd; g.a = x.att; g.lda = (int64_t)nh * hd; g.out = x.hid; g.ldo = H;
-                        launch_gemv(g, GEMV_ACC_F32, x.s);
-                        g.w = L.gate_up.w; g.scales = L.gate_up.scales; g.biases = L.gate_up.biases; g.N = 2 * cfg.inter; g.K = H; g.hid = x.hid; g.norm_w = L.post_norm; g.out = x.act; g.ldo = cfg.inter;
-                        launch_gemv(g, GEMV_NORM_SWIGLU, x.s);
-                        g.w = L.down.w; g.scales = L.down.scales; g.biases = L.down.biases; g.N = H; g.K = cfg.inter; g.a = x.act; g.lda = cfg.inter; g.out = x.hid; g.ldo = H;
-                        launch_gemv(g, GEMV_ACC_F32, x.s);
-                        pend_down[h] = 0;
-                        continue;
-                    }
-                    const int ns_o = proj(x, x.att, (int64_t)nh * hd, L.o, 1, OUT_F32_ACC, x.hid, H);
-                    launch_rmsnorm(x.hid, L.post_norm, x.xn, x.rows, H, cfg.rms_eps, nullptr, x.slab, ns_o, (int64_t)x.rows * H, x.s);
-                    const int ns_gu = proj(x, x.xn, H, L.gate_up, 2, OUT_SWIGLU, x.act, cfg.inter);
-                    if (ns_gu) launch_swiglu_reduce(x.slab, ns_gu, (int64_t)x.rows * 2 * cfg.inter, x.rows, 2 * cfg.inter, x.act, x.s);
-                    pend_down[h] = proj(x, x.act, cfg.inter, L.down, 3, OUT_F32_ACC, x.hid, H);
-                }
+        const size_t per_half = (size_t)max_tokens + 2;
+        std::vector<int> attn_launched(2 * per_half, 0), attn_timed(2 * per_half, 0);
+        // The step of one half is issued in four kinds of pieces.  Every per-step quantity is read from device arrays,
+        // so the launches of all steps between two polls are identical; `it` only feeds the profiler and the logits tap.
+        // pre: [token embedding,] input norm and q/k/v projection of layer l
+        auto pre = [&](int h, int l) {
+            Half& x = hv[h];
+            const DecLayerW& L = m->dec[l];
+            const int* map = st_map[x.cur] + x.r0;
+            if (l == 0)
+                launch_embed_tokens(st_next, map, x.rows, H, qemb ? nullptr : (const bf16_t*)m->embed.w,
+                                    qemb ? (const uint32_t*)m->embed.w : nullptr, m->embed.scales, m->embed.biases, cfg.group_size, x.hid, x.s);
+            if (x.gemv) {  // input norm inside the q/k/v kernel
+                GemvParams g;
+                g.w = L.qkv.w; g.scales = L.qkv.scales; g.biases = L.qkv.biases; g.qgroup = cfg.group_size; g.N = QKV; g.K = H; g.M = x.rows; g.hid = x.hid; g.norm_w = L.in_norm; g.eps = cfg.rms_eps;
+                g.out = x.qkvb; g.ldo = QKV;
+                launch_gemv(g, GEMV_NORM_BF16, x.s);
+                qkv_slabs[h] = 0;
+            } else {
+                // residual += previous layer's down-projection partials (if it left any), then input norm
+                launch_rmsnorm(x.hid, L.in_norm, x.xn, x.rows, H, cfg.rms_eps, nullptr, x.slab, l ? pend_down[h] : 0, (int64_t)x.rows * H, x.s);
+                qkv_slabs[h] = proj(x, x.xn, H, L.qkv, 0, OUT_BF16, x.qkvb, QKV);
             }
-            for (int h = 0; h < n_half; ++h) {
-                const Half& x = hv[h];
-                launch_rmsnorm(x.hid, m->final_norm, x.x_last, x.rows, H, cfg.rms_eps, nullptr, x.slab, pend_down[h], (int64_t)x.rows * H, x.s);
-                lm_head(x.x_last, x.r0, x.rows, it, x.s);
-                step(1, x.r0, x.rows, x.active_dev, st_map[x.cur] + x.r0, st_map[x.cur ^ 1] + x.r0, x.keys + it + 1, x.s);
-                res->decode_rows += x.rows;
+            if (!fuse_rope) {
+                const int ns = qkv_slabs[h];
+                RopeParams rp{ns ? nullptr : x.qkvb, QKV, ns ? x.slab : nullptr, ns, (int64_t)x.rows * QKV, x.qd, (int64_t)nh * hd, x.rows,
+                              nh, nkv, L.q_norm, L.k_norm, cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved,
+                              m->rope_max_pos, map, nullptr, st_len, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride};
+                launch_rope(rp, x.s);
+            }
+            if (chain) HIP_CHECK(hipEventRecord(ev_pre[h][l], x.s));
+        };
+        auto attn = [&](int h, int l, int it) {
+            Half& x = hv[h];
+            const DecLayerW& L = m->dec[l];
+            if (chain) HIP_CHECK(hipStreamWaitEvent(x.sa, ev_pre[h][l], 0));
+            if (prof_active(x.sa)) {
+                const bool timed = prof_next_timed("decode_attn_kernel", x.sa);
+                attn_launched[h * per_half + it] += 1;
+                attn_timed[h * per_half + it] += timed ? 1 : 0;
+                // a timed launch's start event would otherwise be stamped while the stream still waits for the q/k/v rows
+                if (timed && chain) launch_noop(x.sa);
+            }
+            DecodeAttnParams dp{x.qd, (int64_t)nh * hd, kc + l * layer_stride, vc + l * layer_stride, utt_stride, head_stride,
+                                st_len, fuse_rope ? 0 : 1, x.att, (int64_t)nh * hd, x.rows, nkv, nh / nkv, scale};
+            dp.slot = st_map[x.cur] + x.r0;
+            dp.done = skip_done ? st_done : nullptr;
+            if (fuse_rope) {  // q/k norm, RoPE and the cache append happen inside the attention kernel
+                const int ns = qkv_slabs[h];
+                dp.rope = DecodeRopeIn{ns ? nullptr : x.qkvb, ns ? x.slab : nullptr, ns, (int64_t)x.rows * QKV, QKV, L.q_norm, L.k_norm,
+                                       cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos};
+            }
+            launch_decode_attn(dp, hd, x.sa, 0.0);
+            if (chain) HIP_CHECK(hipEventRecord(ev_attn[h][l], x.sa));
+        };
+        // post: o (+= residual), post norm + gate/up + SwiGLU, down (+= residual)
+        auto post = [&](int h, int l) {
+            Half& x = hv[h];
+            const DecLayerW& L = m->dec[l];
+            if (chain) HIP_CHECK(hipStreamWaitEvent(x.s, ev_attn[h][l], 0));
+            if (x.gemv) {
+                GemvParams g;
+                g.M = x.rows; g.eps = cfg.rms_eps; g.qgroup = cfg.group_size;
+                g.w = L.o.w; g.scales = L.o.scales; g.biases = L.o.biases; g.N = H; g.K = nh * hd; g.a = x.att; g.lda = (int64_t)nh * hd; g.out = x.hid; g.ldo = H;
+                launch_gemv(g, GEMV_ACC_F32, x.s);
+                g.w = L.gate_up.w; g.scales = L.gate_up.scales; g.biases = L.gate_up.biases; g.N = 2 * cfg.inter; g.K = H; g.hid = x.hid; g.norm_w = L.post_norm; g.out = x.act; g.ldo = cfg.inter;
+                launch_gemv(g, GEMV_NORM_SWIGLU, x.s);
+                g.w = L.down.w; g.scales = L.down.scales; g.biases = L.down.biases; g.N = H; g.K = cfg.inter; g.a = x.act; g.lda = cfg.inter; g.out = x.hid; g.ldo = H;
+                launch_gemv(g, GEMV_ACC_F32, x.s);
+                pend_down[h] = 0;
+                return;
+            }
+            const int ns_o = proj(x, x.att, (int64_t)nh * hd, L.o, 1, OUT_F32_ACC, x.hid, H);
+            launch_rmsnorm(x.hid, L.post_norm, x.xn, x.rows, H, cfg.rms_eps, nullptr, x.slab, ns_o, (int64_t)x.rows * H, x.s);
+            const int ns_gu = proj(x, x.xn, H, L.gate_up, 2, OUT_SWIGLU, x.act, cfg.inter);
+            if (ns_gu) launch_swiglu_reduce(x.slab, ns_gu, (int64_t)x.rows * 2 * cfg.inter, x.rows, 2 * cfg.inter, x.act, x.s);
+            pend_down[h] = proj(x, x.act, cfg.inter, L.down, 3, OUT_F32_ACC, x.hid, H);
+        };
+        // tail: final norm, LM head, bookkeeping
+        auto tail = [&](int h, int it) {
+            Half& x = hv[h];
+            launch_rmsnorm(x.hid, m->final_norm, x.x_last, x.rows, H, cfg.rms_eps, nullptr, x.slab, pend_down[h], (int64_t)x.rows * H, x.s);
+            lm_head(x.x_last, x.r0, x.rows, it, x.s);
+            step(1, x.r0, x.rows, x.active_dev, st_map[x.cur] + x.r0, st_map[x.cur ^ 1] + x.r0, x.keys + it + 1, x.s);
+            res->decode_rows += x.rows;
+        };
+        // With two halves the attention stream runs A(0,l) A(1,l) A(0,l+1) ... and the other stream post(0,l) pre(0,l+1)
+        // post(1,l) pre(1,l+1) ...: while one half's attention streams the cache, the other half's projections run.
+        // A half's first `pre` of the next step follows its bookkeeping at once (`more`: another step will be issued),
+        // so that the next step's first attention does not wait for the other half's LM head.
+        auto issue_step = [&](int it, bool more) {
+            for (int h = 0; h < n_half; ++h)
+                if (hv[h].rows > 0 && !hv[h].pre_issued) pre(h, 0);
+            for (int l = 0; l < cfg.layers; ++l) {
+                for (int h = 0; h < n_half; ++h)
+                    if (hv[h].rows > 0) attn(h, l, it);
+                for (int h = 0; h < n_half; ++h) {
+                    if (hv[h].rows == 0) continue;
+                    post(h, l);
+                    if (l + 1 < cfg.layers) {
+                        pre(h, l + 1);
+                    } else {
+                        tail(h, it);
+                        hv[h].pre_issued = n_half == 2 && more;
+                        if (hv[h].pre_issued) pre(h, 0);
+                    }
+                }
             }
         };
         // (Dealing one head's keys to several workgroups with a last-arriver merge was measured at one utterance: no gain,
         // the kernel's fixed prologue and the merge's fences cost what the shorter key loop saves.)
         // (Replaying the step as a HIP graph was measured at 1, 8, 32 and 64 utterances: no change -- even one
         // utterance is bound by streaming the 3.4 GB of weights per step, not by the host's launch rate.)
+        const char* env_merge = getenv("Q3ASR_DECODE_MERGE_ROWS");
+        const int merge_rows = std::min(env_merge ? atoi(env_merge) : SPLIT_MERGE_ROWS, hv[0].n);
         for (int it = 1; it < max_tokens && active > 0; ++it) {
-            issue_step(it);
+            const bool poll = it % POLL_STEPS == 0 || it + 1 == max_tokens;
+            issue_step(it, it + 1 < max_tokens);
             res->decode_steps += 1;
-            if (it % POLL_STEPS == 0 || it + 1 == max_tokens) {
-                int act_h[2] = {0, 0};
-                for (int h = 0; h < n_half; ++h) HIP_CHECK(hipMemcpyAsync(&act_h[h], hv[h].active_dev, 4, hipMemcpyDeviceToHost, hv[h].s));
-                for (int h = 0; h < n_half; ++h) HIP_CHECK(hipStreamSynchronize(hv[h].s));
-                active = act_h[0] + act_h[1];
-                if (retire && active > 0 && active < hv[0].rows) {
-                    // the step just finished wrote the running utterances into the other list: decode those rows from now on
-                    hv[0].cur ^= 1;
-                    set_rows(hv[0], active);
-                }
+            if (!poll) continue;
+            int act_h[2] = {0, 0};
+            for (int h = 0; h < n_half; ++h)
+                if (hv[h].rows > 0) HIP_CHECK(hipMemcpyAsync(&act_h[h], hv[h].active_dev, 4, hipMemcpyDeviceToHost, hv[h].s));
+            for (int h = 0; h < n_half; ++h) HIP_CHECK(hipStreamSynchronize(hv[h].s));   // (the attention stream has drained before the bookkeeping ran)
+            active = act_h[0] + act_h[1];
+            if (!retire || active == 0) continue;
+            for (int h = 0; h < n_half; ++h) {
+                Half& x = hv[h];
+                if (x.rows == 0 || act_h[h] == x.rows) continue;
+                // the step just finished wrote the running utterances into the other list: decode those rows from now on
+                x.cur ^= 1;
+                if (act_h[h] > 0) set_rows(x, act_h[h]);
+                else x.rows = 0;
+            }
+            if (n_half == 2 && (active <= merge_rows || hv[0].rows == 0 || hv[1].rows == 0)) {
+                // Too few rows for two halves to pay (or one half has finished): one list, one stream, every CU again.
+                // Both streams are idle here; the lists are joined through a staging array (source and destination
+                // ranges of one list array may overlap).
+                int o = 0;
+                for (int h = 0; h < 2; ++h)
+                    if (hv[h].rows > 0) {
+                        HIP_CHECK(hipMemcpyAsync(st_tmp + o, st_map[hv[h].cur] + hv[h].r0, (size_t)hv[h].rows * 4, hipMemcpyDeviceToDevice, c.s));
+                        o += hv[h].rows;
+                    }
+                HIP_CHECK(hipMemcpyAsync(st_map[0], st_tmp, (size_t)o * 4, hipMemcpyDeviceToDevice, c.s));
+                n_half = 1;
+                chain = false;
+                cur_cus = 0;
+                Half& x = hv[0];
+                x.r0 = 0; x.cur = 0; x.s = x.sa = c.s; x.x_last = x_last;
+                pend_down[0] = 0;
+                set_rows(x, o);
             }
         }
-        if (n_half == 2) {  // everything after the loop runs on the main stream
-            HIP_CHECK(hipEventRecord(ev_join, m->stream2));
+        if (was_split && n_half == 2) {  // everything after the loop runs on the main stream
+            HIP_CHECK(hipEventRecord(ev_join, m->stream_mm));
+            HIP_CHECK(hipStreamWaitEvent(c.s, ev_join, 0));
+            HIP_CHECK(hipEventRecord(ev_join, m->stream_att));
             HIP_CHECK(hipStreamWaitEvent(c.s, ev_join, 0));
         }
-        if (prof_active(c.s) && exact_work) {
-            std::vector<long long> keys(max_tokens + 2);
+        cur_cus = 0;
+        if (prof_active(c.s)) {
+            std::vector<long long> keys(2 * per_half);
             HIP_CHECK(hipMemcpyAsync(keys.data(), st_keys, keys.size() * sizeof(long long), hipMemcpyDeviceToHost, c.s));
             HIP_CHECK(hipStreamSynchronize(c.s));
             double total = 0, timed = 0;
-            for (int it = 1; it < max_tokens; ++it) {
-                const double bytes = 2.0 * 2.0 * nkv * hd * (double)keys[it];   // K and V rows, bf16, every kv head
-                total += bytes * attn_launched[it];
-                timed += bytes * attn_timed[it];
-            }
+            for (int h = 0; h < 2; ++h)
+                for (int it = 1; it < max_tokens; ++it) {
+                    const double bytes = 2.0 * 2.0 * nkv * hd * (double)keys[h * per_half + it];   // K and V rows, bf16, every kv head
+                    total += bytes * attn_launched[h * per_half + it];
+                    timed += bytes * attn_timed[h * per_half + it];
+                }
             prof_add_work("decode_attn_kernel", total, timed, c.s);
         }
     }
@@ -1036,3 +1140,5 @@ void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* re
         transcribe_group(c, req, res, idx, tap_a_off, tap_s_off);
     }
 }
+
+int model_decode_att_cus(int n_utt) { return decode_att_cus(n_utt); }

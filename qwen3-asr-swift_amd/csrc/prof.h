@@ -6,8 +6,10 @@
 #include "common.h"
 #include <string>
 
-// Starts a profile over launches on streams s0 and s1 (s1 may be null).
-void prof_start(hipStream_t s0, hipStream_t s1, int stride);
+// Starts a profile over launches on stream s0.
+void prof_start(hipStream_t s0, int stride);
+// Makes launches on stream `extra` part of the profile that owns stream s (no-op when none is running).
+void prof_attach(hipStream_t s, hipStream_t extra);
 // Stops the profile that owns stream s, waits for the device, and returns a JSON array of
 // {"name", "launches", "timed", "ms_timed", "work", "work_timed"} objects ("[]" when none was running).
 std::string prof_stop(hipStream_t s);

@@ -42,13 +42,23 @@ bool prof_active(hipStream_t s) {
     return find(s) != nullptr;
 }
 
-void prof_start(hipStream_t s0, hipStream_t s1, int stride) {
+void prof_start(hipStream_t s0, int stride) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!find(s0)) g_running.fetch_add(1);
+    if (const auto old = find(s0)) {   // restarted: drop every stream of the old profile
+        for (auto it = g_by_stream.begin(); it != g_by_stream.end();)
+            it = it->second == old ? g_by_stream.erase(it) : std::next(it);
+    } else {
+        g_running.fetch_add(1);
+    }
     auto st = std::make_shared<State>();
     st->stride = stride < 1 ? 1 : stride;
     g_by_stream[s0] = st;
-    if (s1) g_by_stream[s1] = st;
+}
+
+void prof_attach(hipStream_t s, hipStream_t extra) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const auto st = find(s);
+    if (st && extra) g_by_stream[extra] = st;
 }
 
 int prof_begin(const char* name, double work, hipStream_t s) {

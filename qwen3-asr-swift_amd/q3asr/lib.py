@@ -42,7 +42,7 @@ EXPORTS = [
     "q3asr_last_error", "q3asr_create", "q3asr_destroy", "q3asr_load_tensor", "q3asr_finalize", "q3asr_mel_filterbank",
     "q3asr_mel", "q3asr_encode", "q3asr_output_length", "q3asr_transcribe_tokens", "q3asr_op_gemm", "q3asr_op_gemm_q4",
     "q3asr_op_attention", "q3asr_profile_start", "q3asr_profile_stop", "q3asr_op_gemm_time", "q3asr_op_greedy_rules",
-    "q3asr_op_read_bandwidth", "q3asr_op_mfma_f32_rate", "q3asr_workspace_bytes", "q3asr_mel_noalloc",
+    "q3asr_op_read_bandwidth", "q3asr_op_mfma_f32_rate", "q3asr_workspace_bytes", "q3asr_mel_noalloc", "q3asr_decode_attention_cus",
 ]
 
 
@@ -66,6 +66,8 @@ def load():
     lib.q3asr_output_length.argtypes = [c_void_p, c_int]
     lib.q3asr_workspace_bytes.argtypes = [c_void_p]
     lib.q3asr_workspace_bytes.restype = ctypes.c_int64
+    lib.q3asr_decode_attention_cus.argtypes = [c_void_p, c_int]
+    lib.q3asr_decode_attention_cus.restype = c_int
     lib.q3asr_transcribe_tokens.argtypes = [c_void_p, P(Q3Request), P(Q3Result)]
     lib.q3asr_op_gemm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.q3asr_op_gemm_q4.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]

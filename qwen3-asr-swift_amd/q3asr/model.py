@@ -315,6 +315,10 @@ class Qwen3ASRModel:
         """Device memory the per-call workspace holds at the moment."""
         return int(self._lib.q3asr_workspace_bytes(self._h))
 
+    def decode_attention_cus(self, n_utt):
+        """Compute units the decode attention of a group of n_utt utterances is confined to (0: one stream)."""
+        return int(self._lib.q3asr_decode_attention_cus(self._h, int(n_utt)))
+
     # ---- per-kernel timing ----
     def profile_start(self, stride=1):
         _lib.check(self._lib, self._lib.q3asr_profile_start(self._h, int(stride)))

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <set>
 #include <map>
@@ -26,6 +27,20 @@ __global__ void where_kernel(unsigned* out) {
 }
 
 // 256 threads, each wave keeps 16 x 1 KB requests in flight (like the decode attention's two tiles)
+template <int NL, int WPC>
+__global__ __launch_bounds__(256, WPC) void read_kernel_t(const u32x4* __restrict__ src, size_t n_vec, unsigned* sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; i + (NL - 1) * stride < n_vec; i += NL * stride) {
+        u32x4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) acc ^= v[k];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
 __global__ __launch_bounds__(256, 3) void read_kernel(const u32x4* __restrict__ src, size_t n_vec, unsigned* sink) {
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -36,6 +51,100 @@ __global__ __launch_bounds__(256, 3) void read_kernel(const u32x4* __restrict__ 
         for (int k = 0; k < 16; ++k) v[k] = __builtin_nontemporal_load(src + i + k * stride);
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc ^= v[k];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
+}
+
+// The decode attention's request pattern without its arithmetic: per wave and 16-key tile, the K rows as four 16-byte
+// loads per lane (16 rows x 64 B per instruction) and the V rows either as sixteen 4-byte loads per lane (one 256 B
+// row per instruction, MODE 0) or as four 16-byte loads per lane (four rows per instruction, MODE 1).  Two tiles in flight.
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void pattern_kernel(const unsigned char* __restrict__ kbase, const unsigned char* __restrict__ vbase,
+                                                          int tiles_per_wave, unsigned* sink) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const size_t wave_id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned char* kp = kbase + wave_id * tiles_per_wave * 4096;
+    const unsigned char* vp = vbase + wave_id * tiles_per_wave * 4096;
+    u32x4 acc = {0, 0, 0, 0};
+    unsigned acc1 = 0;
+    u32x4 kf[2][4];
+    u32x4 v4[2][4];
+    unsigned v1[2][16];
+    auto load = [&](int b, int t) {
+        const unsigned char* k = kp + (size_t)t * 4096 + li * 256 + lg * 16;
+        if (MODE != 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[b][ks] = __builtin_nontemporal_load((const u32x4*)(k + 64 * ks));
+        }
+        if (MODE == 2) {   // K rows coalesced as well: every 128-byte line is touched by one instruction only
+            const unsigned char* k2 = kp + (size_t)t * 4096 + (4 * lg) * 256 + li * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kf[b][i] = __builtin_nontemporal_load((const u32x4*)(k2 + 256 * i));
+        }
+        if (MODE == 0) {
+            const unsigned char* v = vp + (size_t)t * 4096 + lane * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v1[b][r] = __builtin_nontemporal_load((const unsigned*)(v + 256 * r));
+        } else {
+            const unsigned char* v = vp + (size_t)t * 4096 + (4 * lg) * 256 + li * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v4[b][i] = __builtin_nontemporal_load((const u32x4*)(v + 256 * i));
+        }
+    };
+    auto use = [&](int b) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc ^= kf[b][ks];
+        if (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1 ^= v1[b][r];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc ^= v4[b][i];
+        }
+    };
+    load(0, 0);
+    for (int t = 0; t + 1 < tiles_per_wave; t += 2) {
+        load(1, t + 1);
+        use(0);
+        if (t + 2 < tiles_per_wave) load(0, t + 2);
+        use(1);
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w ^ acc1) == 0x12345u) sink[0] = 1;
+}
+
+// The same bytes requested as 16-byte-per-lane loads that land in LDS without passing through registers
+// (two tiles of K and V per wave = 16 KB, 64 KB per workgroup), then read back from LDS.
+__global__ __launch_bounds__(256, 2) void lds_pattern_kernel(const unsigned char* __restrict__ kbase, const unsigned char* __restrict__ vbase,
+                                                              int tiles_per_wave, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wave_id = (size_t)blockIdx.x * 4 + wave;
+    const unsigned char* kp = kbase + wave_id * tiles_per_wave * 4096 + lane * 16;
+    const unsigned char* vp = vbase + wave_id * tiles_per_wave * 4096 + lane * 16;
+    unsigned char* mine = lds + wave * 16384;
+    u32x4 acc = {0, 0, 0, 0};
+    auto load = [&](int b, int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + (size_t)t * 4096 + 1024 * i),
+                                             (__attribute__((address_space(3))) void*)(mine + b * 8192 + 1024 * i), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + (size_t)t * 4096 + 1024 * i),
+                                             (__attribute__((address_space(3))) void*)(mine + b * 8192 + 4096 + 1024 * i), 16, 0, 0);
+        }
+    };
+    auto use = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc ^= *(const u32x4*)(mine + b * 8192 + 1024 * i + lane * 16);
+    };
+    load(0, 0);
+    for (int t = 0; t + 1 < tiles_per_wave; t += 2) {
+        load(1, t + 1);
+        __builtin_amdgcn_s_waitcnt(0x0f70 | 8);   // vmcnt(8): the older tile has landed
+        use(0);
+        if (t + 2 < tiles_per_wave) load(0, t + 2);
+        if (t + 2 < tiles_per_wave) __builtin_amdgcn_s_waitcnt(0x0f70 | 8);
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        use(1);
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = 1;
 }
@@ -57,12 +166,31 @@ __global__ __launch_bounds__(512) void mfma_kernel(float* out, int iters) {
 static hipStream_t masked_stream(const std::vector<int>& bits) {
     std::vector<uint32_t> mask(8, 0);
     for (int b : bits) mask[b >> 5] |= 1u << (b & 31);
-    hipStream_t s;
-    CK(hipExtStreamCreateWithCUMask(&s, 8, mask.data()));
+    hipStream_t s = nullptr;
+    printf("[mask %zu bits] ", bits.size());
+    CK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    printf("[stream %p] ", (void*)s);
     return s;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    if (argc >= 4 && !strcmp(argv[1], "try")) {   // try <mask words> <bits set>: does stream creation work at all?
+        const int words = atoi(argv[2]), nbits = atoi(argv[3]);
+        std::vector<uint32_t> mask(words, 0);
+        for (int b = 0; b < nbits; ++b) mask[b >> 5] |= 1u << (b & 31);
+        int rv = 0, dv = 0;
+        CK(hipRuntimeGetVersion(&rv));
+        CK(hipDriverGetVersion(&dv));
+        printf("runtime %d driver %d: mask of %d words, %d bits ... ", rv, dv, words, nbits);
+        hipStream_t s = nullptr;
+        CK(hipStreamCreate(&s));
+        printf("plain stream ok; ");
+        hipStream_t sm = nullptr;
+        hipError_t e = hipExtStreamCreateWithCUMask(&sm, (uint32_t)words, mask.data());
+        printf("masked stream: %s\n", hipGetErrorString(e));
+        return 0;
+    }
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -95,12 +223,15 @@ int main() {
         printf(" -> %zu distinct CUs\n", total);
         CK(hipStreamDestroy(s));
     };
-    where({0}, "bit 0");
-    where({1}, "bit 1");
-    where({8}, "bit 8");
-    where({0, 1, 2, 3, 4, 5, 6, 7}, "bits 0-7");
-    { std::vector<int> b; for (int i = 0; i < 96; ++i) b.push_back(i); where(b, "bits 0-95"); }
-    { std::vector<int> b; for (int i = 0; i < cus; ++i) b.push_back(i); where(b, "all bits"); }
+    if (argc >= 4 && !strcmp(argv[1], "where")) {   // where <first bit> <last bit> [step]
+        std::vector<int> b;
+        const int step = argc >= 5 ? atoi(argv[4]) : 1;
+        for (int i = atoi(argv[2]); i <= atoi(argv[3]); i += step) b.push_back(i);
+        char label[64];
+        snprintf(label, sizeof label, "bits %s-%s step %d", argv[2], argv[3], step);
+        where(b, label);
+        return 0;
+    }
 
     // (2) read bandwidth against the CU count (bits 0 .. n-1), alone
     const size_t bytes = (size_t)8 << 30;
@@ -113,6 +244,70 @@ int main() {
     CK(hipMalloc(&fout, 64));
     hipEvent_t e0, e1, f0, f1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+    if (argc >= 2 && !strcmp(argv[1], "pattern")) {   // the attention's load pattern against the CU count
+        for (int n : {96, 128, 160, 248}) {
+            std::vector<int> ba;
+            for (int i = 0; i < n; ++i) ba.push_back(i);
+            hipStream_t sa = masked_stream(ba);
+            printf("\n");
+            const int tiles = 28;                       // ~450 keys per (utterance, head) item, as a workgroup of the decode kernel sees
+            const int grid = (int)((bytes / 2) / ((size_t)tiles * 4096 * 4));
+            auto run = [&](auto kern, const char* label) {
+                const unsigned char* kb = (const unsigned char*)src;
+                const unsigned char* vb = kb + bytes / 2;
+                const int ldsb = (void*)kern == (void*)lds_pattern_kernel ? 65536 : 0;
+                if (ldsb) CK(hipFuncSetAttribute((const void*)lds_pattern_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, sa, kb, vb, tiles, sink);
+                CK(hipStreamSynchronize(sa));
+                CK(hipEventRecord(e0, sa));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, sa, kb, vb, tiles, sink);
+                CK(hipEventRecord(e1, sa));
+                CK(hipStreamSynchronize(sa));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const double moved = (double)grid * 4 * tiles * 8192;
+                printf("  %3d CUs, %s: %.2f TB/s = %.1f GB/s per CU\n", n, label, moved / ms * 1e-9, moved / ms * 1e-6 / n);
+            };
+            run(pattern_kernel<0>, "V as 16 x 4 B per lane ");
+            run(pattern_kernel<1>, "V as  4 x 16 B per lane");
+            run(pattern_kernel<2>, "K and V as 4 x 16 B per lane, whole rows");
+            run(lds_pattern_kernel, "K and V as 16 B per lane straight into LDS (2 workgroups/CU)");
+            CK(hipStreamDestroy(sa));
+        }
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "inflight")) {   // bandwidth against the bytes in flight per CU
+        for (int n : {96, 128, 160}) {
+            std::vector<int> ba;
+            for (int i = 0; i < n; ++i) ba.push_back(i);
+            hipStream_t sa = masked_stream(ba);
+            printf("\n");
+            auto run = [&](auto kern, int nl, int wpc) {
+                const int grid = wpc * n;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, sa, src, bytes / 16, sink);
+                CK(hipStreamSynchronize(sa));
+                CK(hipEventRecord(e0, sa));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, sa, src, bytes / 16, sink);
+                CK(hipEventRecord(e1, sa));
+                CK(hipStreamSynchronize(sa));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  %3d CUs, %2d x 16 B per lane, %d workgroups/CU (%3d KB in flight per CU): %.2f TB/s = %.1f GB/s per CU\n", n, nl, wpc,
+                       nl * 16 * 256 * wpc / 1024, bytes / ms * 1e-9, bytes / ms * 1e-6 / n);
+            };
+            run(read_kernel_t<4, 4>, 4, 4);
+            run(read_kernel_t<8, 4>, 8, 4);
+            run(read_kernel_t<8, 8>, 8, 8);
+            run(read_kernel_t<16, 3>, 16, 3);
+            run(read_kernel_t<16, 4>, 16, 4);
+            run(read_kernel_t<16, 6>, 16, 6);
+            run(read_kernel_t<32, 2>, 32, 2);
+            run(read_kernel_t<32, 3>, 32, 3);
+            run(read_kernel_t<48, 2>, 48, 2);
+            CK(hipStreamDestroy(sa));
+        }
+        return 0;
+    }
     const int ns[] = {32, 64, 96, 128, 160, 192, 256};
     for (int n : ns) {
         if (n > cus) continue;

@@ -155,19 +155,22 @@ def test_ragged_corpus_in_groups(monkeypatch):
         m.close()
 
 
-def test_two_stream_decode_equals_one_stream(pinned_model, monkeypatch):
-    """Large groups are decoded as two halves on two event-chained streams; a small group is forced through that
-    path here and must give the tokens (and stop points) of the single-stream loop."""
+def test_split_decode_equals_one_stream(pinned_model, monkeypatch):
+    """Large groups are decoded as two halves, their attention kernels on a stream confined to part of the compute
+    units and everything else on a stream confined to the rest; a small group is forced through that path here and
+    must give the tokens (and stop points) of the single-stream loop."""
     m, cfg, _ = pinned_model
     audios = [synth.synth_audio(n, 80 + i) for i, n in enumerate((20000, 100000, 16000, 64000, 33333))]
-    monkeypatch.setenv("Q3ASR_DECODE_STREAMS", "1")
+    monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "0")
     one = m.transcribe_batch(audios, 16000, max_tokens=24)
-    monkeypatch.setenv("Q3ASR_DECODE_STREAMS", "2")
-    two = m.transcribe_batch(audios, 16000, max_tokens=24)
-    assert one.tokens == two.tokens
+    for att_cus in ("160", "64"):
+        monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", att_cus)
+        two = m.transcribe_batch(audios, 16000, max_tokens=24)
+        assert one.tokens == two.tokens, att_cus
+        assert one.decode_steps == two.decode_steps
     forced = np.tile(np.arange(100, 110, dtype=np.int32), (5, 1))
     a = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
-    monkeypatch.setenv("Q3ASR_DECODE_STREAMS", "1")
+    monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "0")
     b = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
     assert _rel(a.taps["logits"], b.taps["logits"]) <= 1e-3
 

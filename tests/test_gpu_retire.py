@@ -119,3 +119,33 @@ def test_free_running_stops_retire_too(pinned_model, monkeypatch):
     drop = m.transcribe_batch(audios, 16000, max_tokens=96, lang_ids=prefix)
     assert drop.tokens == keep.tokens
     assert drop.decode_rows <= keep.decode_rows
+
+
+@pytest.mark.parametrize("merge_rows", [0, 4, 100])
+def test_split_decode_retires_and_merges(pinned_model, monkeypatch, merge_rows):
+    """The two-half decode (attention on its own share of the compute units) drops finished rows per half and goes
+    back to one list on one stream when few utterances are left (merge_rows) or a half has emptied (here: half 0
+    holds only early stops): the tokens are those of the single-stream run that keeps every row."""
+    m, cfg, ck = pinned_model
+    max_tokens = 44
+    stops = [0, 3, 9, 10, 2, 6, None, 17, 25, 33, 40]          # half 0 = utterances 0-5, half 1 = 6-10
+    audios = [synth.synth_audio(16000 + 3000 * i, 900 + i) for i in range(len(stops))]
+    forced = _script(len(stops), max_tokens, stops, seed=6)
+    want_counts = _expected_counts(forced, max_tokens)
+    monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "0")
+    monkeypatch.setenv("Q3ASR_RETIRE", "0")
+    keep = m.transcribe_batch(audios, 16000, max_tokens=max_tokens, forced_tokens=forced, stop_rules="forced")
+    assert [len(t) for t in keep.tokens] == want_counts
+    monkeypatch.setenv("Q3ASR_RETIRE", "1")
+    monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "160")
+    monkeypatch.setenv("Q3ASR_DECODE_MERGE_ROWS", str(merge_rows))
+    split = m.transcribe_batch(audios, 16000, max_tokens=max_tokens, forced_tokens=forced, stop_rules="forced")
+    assert split.tokens == keep.tokens
+    assert split.decode_steps == max_tokens - 1
+    upper = sum(min(max_tokens - 1, n - 1 + 8) for n in want_counts)
+    assert sum(n - 1 for n in want_counts) <= split.decode_rows <= upper < keep.decode_rows
+    # and with every row kept, the two-half loop alone
+    monkeypatch.setenv("Q3ASR_RETIRE", "0")
+    split_keep = m.transcribe_batch(audios, 16000, max_tokens=max_tokens, forced_tokens=forced, stop_rules="forced")
+    assert split_keep.tokens == keep.tokens
+    assert split_keep.decode_rows == keep.decode_rows
