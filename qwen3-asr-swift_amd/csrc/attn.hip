@@ -13,8 +13,10 @@
 // K/V stream).  HBM-bound: K and V are requested as whole 256-byte rows (a load instruction that takes a
 // 64-byte piece of 16 rows -- the MFMA A-fragment shape -- touches every 128-byte line twice, and a compute unit
 // then sustains 34 instead of 50 GB/s: measured with the bare request patterns, scripts/probe_cu_mask.hip); the
-// K rows become A fragments through a wave-private LDS tile, the probabilities are broadcast with v_readlane,
-// V rows are consumed by the VALU.
+// K rows become A fragments of S^T = K Q^T through a wave-private LDS tile; the exponentiated scores, rounded to bf16,
+// are as they stand the B operand of O^T = V^T P^T, whose A fragments are transposing LDS reads of the V tile.  The
+// vector ALU only does the softmax: with the products on it (fp32 FMAs over broadcast probabilities) a compute
+// unit could not issue fast enough to keep its share of the HBM stream when the kernel is confined to 160 CUs.
 #include "attn.h"
 #include <cstdlib>
 #include "prof.h"
@@ -23,6 +25,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 namespace {
 
@@ -179,17 +182,30 @@ template <int GROUP, bool FUSED, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_kernel(DecodeAttnParams p) {
     constexpr int D = 128;
     __shared__ float sm_m[WAVES][GROUP], sm_l[WAVES][GROUP];
-    __shared__ float so[WAVES][GROUP][D];
-    __shared__ __attribute__((aligned(16))) bf16_t sq[GROUP][D];  // FUSED: this step's normalised, rotated queries
-    __shared__ float snew[2][D];                                  // FUSED: the new key (rotated) and value, bf16-rounded
+    __shared__ __attribute__((aligned(16))) float so[WAVES][GROUP][D];
+    // this step's queries (FUSED: normalised and rotated here), as the 16 rows of the B operand: rows >= GROUP stay zero;
+    // read per tile rather than held in registers (the accumulators and two tiles in flight need them)
+    __shared__ __attribute__((aligned(16))) bf16_t sq[16][D + 8];
+    __shared__ __attribute__((aligned(16))) float snew[2][D];     // FUSED: the new key (rotated) and value, bf16-rounded
     // per wave: one 16-key K tile, rows padded to 272 bytes so that both the row-wise writes and the fragment reads
     // (16 rows, one 16-byte chunk each) spread over all banks
     constexpr int KROW = 2 * D + 16;
     __shared__ __attribute__((aligned(16))) char ktile[WAVES][16 * KROW];
+    // and one V tile, rows padded to 288 bytes: the transposing read takes, per 16 lanes, 4 rows x 16 columns with
+    // four lanes (32 bytes) per row, and rows 32 bytes apart modulo the banks keep the two groups of a half-wave apart
+    constexpr int VROW = 2 * D + 32;
+    __shared__ __attribute__((aligned(16))) char vtile[WAVES][16 * VROW];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: tile indices and loop branches stay scalar
     char* const kw = ktile[wave] + (4 * lg) * KROW + 16 * li;        // this lane's chunk of rows 4 lg .. 4 lg + 3
     const char* const kr = ktile[wave] + li * KROW + 16 * lg;        // fragment ks of key row li: + 64 ks
+    const char* const qr = (const char*)&sq[li][8 * lg];             // fragment ks of query li: + 64 ks
+    for (int idx = tid; idx < 16 * (D + 8) / 2; idx += 64 * WAVES) ((uint32_t*)&sq[0][0])[idx] = 0u;
+    __syncthreads();
+    char* const vw = vtile[wave] + (4 * lg) * VROW + 16 * li;
+    // lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of the group's block (keys 4 lg .. 4 lg + 3,
+    // dims 16 dt .. 16 dt + 15) and receives column (lane & 15) of the four rows: the A fragment of a 16x16x16 MFMA
+    const char* const vr = vtile[wave] + (4 * lg + (li >> 2)) * VROW + 8 * (li & 3);   // + 32 dt
     // (utterance, kv head) work items, strided over the grid: the launcher may cap the grid so that a fixed
     // number of workgroups per CU stream the cache while another stream's kernels share the CUs
     const int items = p.B * p.kv_heads;
@@ -207,43 +223,49 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     const bf16_t* Vb = p.V + (int64_t)u * p.utt_stride + (int64_t)kvh * p.head_stride;
     const float sl2 = p.scale * 1.44269504088896340736f;
     float m = -INFINITY, l = 0.f;
-    float o[GROUP][2];
+    f32x4 o[D / 16];   // O^T accumulators: lane (q, lg) holds dims 16 dt + 4 lg + r of query q (lanes q >= GROUP are padding)
 #pragma unroll
-    for (int q = 0; q < GROUP; ++q) o[q][0] = o[q][1] = 0.f;
+    for (int dt = 0; dt < D / 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Tiles of 16 keys, round-robin over the four waves.  The next tile's K fragments and V rows are
-    // requested before the current tile is consumed, so every wave keeps two tiles (16 KB) in flight.
+    // Tiles of 16 keys, round-robin over the waves.  A tile's K rows wait in registers until the previous tile's scores
+    // are done, move to LDS, and the registers are at once reloaded with the next tile's K rows; the V rows follow the
+    // same way after the softmax.  So about one tile (8 KB) per wave is in flight at any time behind one register copy.
     // Loads use one base address per tile plus immediate offsets (no per-row clamping) and are marked non-temporal:
     // the cache is read once per step, and streaming loads that do not displace L2 lines sustain ~15 % more HBM
     // bandwidth on this GPU than plain ones (6.9 against 6.0 TB/s in a bare read loop).
-#define DA_LOAD(KF, VV, T)                                                                                     \
+    // Rows past len-1 are allocated padding (the cache holds 16 spare rows); they are masked in the last tile.
+#define DA_LOAD_K(T)                                                                                           \
     {                                                                                                          \
-        const int kv0_ = (T) * 16;                                                                             \
-        /* rows past len-1 are allocated padding (the cache holds 16 spare rows); they are masked below */    \
-        const bf16_t* kp_ = Kb + (int64_t)(kv0_ + 4 * lg) * D + 8 * li;   /* 16 lanes per row */             \
+        const bf16_t* kp_ = Kb + (int64_t)((T) * 16 + 4 * lg) * D + 8 * li;   /* 16 lanes per row */         \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-            KF[i].v = __builtin_nontemporal_load((const bf16x8*)(kp_ + i * D));                               \
-        const bf16_t* vp_ = Vb + (int64_t)kv0_ * D + 2 * lane;                                                 \
-        _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                         \
-            VV[k] = __builtin_nontemporal_load((const uint32_t*)(vp_ + k * D));                               \
+            kf[i].v = __builtin_nontemporal_load((const bf16x8*)(kp_ + i * D));                               \
     }
-#define DA_COMPUTE(KF, VV, T, MASK)                                                                               \
+#define DA_LOAD_V(T)                                                                                           \
+    {                                                                                                          \
+        const bf16_t* vp_ = Vb + (int64_t)((T) * 16 + 4 * lg) * D + 8 * li;                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+            vf[i].v = __builtin_nontemporal_load((const bf16x8*)(vp_ + i * D));                               \
+    }
+    // LAST: the wave's last tile (nothing more to request; keys past len are masked)
+#define DA_TILE(T, LAST)                                                                                       \
     {                                                                                                          \
         const int kv0 = (T) * 16;                                                                              \
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) *(uint4*)(kw + i * KROW) = KF[i].u;                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) *(uint4*)(kw + i * KROW) = kf[i].u;                      \
+        if (!(LAST)) DA_LOAD_K((T) + WAVES);                                                                   \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                 \
         __builtin_amdgcn_wave_barrier();                                                                       \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                 \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                     \
-            Frag ka_;                                                                                          \
+            Frag ka_, qb_;                                                                                     \
             ka_.u = *(const uint4*)(kr + 64 * ks);                                                             \
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka_.v, qf[ks].v, s, 0, 0, 0);                          \
+            qb_.u = *(const uint4*)(qr + 64 * ks);                                                             \
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka_.v, qb_.v, s, 0, 0, 0);                             \
         }                                                                                                      \
         __builtin_amdgcn_wave_barrier();   /* the next tile's rows are written after these reads */            \
         float sv[4], tmax = -INFINITY;                                                                         \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                        \
-            sv[r] = (!(MASK) || kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;                              \
+            sv[r] = (!(LAST) || kv0 + 4 * lg + r < len) ? s[r] * sl2 : -INFINITY;                              \
             tmax = fmaxf(tmax, sv[r]);                                                                         \
         }                                                                                                      \
         tmax = rows_max(tmax);                                                                                 \
@@ -257,26 +279,34 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
         ps = rows_sum(ps);                                                                                     \
         l = l * alpha + ps;                                                                                    \
         m = m_new;                                                                                             \
-        /* lane (q + 16 g) holds the probabilities of keys 4 g .. 4 g + 3 for query q: broadcast them */       \
-        _Pragma("unroll") for (int q = 0; q < GROUP; ++q) {                                                    \
-            const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(alpha), q));               \
-            float ox = o[q][0] * a, oy = o[q][1] * a;                                                          \
-            _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                   \
-                const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr[k & 3]), q + 16 * (k >> 2))); \
-                const uint32_t vk = (!(MASK) || kv0 + k < len) ? VV[k] : 0u;                                   \
-                ox = fmaf(pk, __uint_as_float(vk << 16), ox);                                                  \
-                oy = fmaf(pk, __uint_as_float(vk & 0xffff0000u), oy);                                          \
-            }                                                                                                  \
-            o[q][0] = ox;                                                                                      \
-            o[q][1] = oy;                                                                                      \
+        /* lane (q, lg) holds the probabilities of keys 4 lg .. 4 lg + 3 for query q: the B fragment of P^T */  \
+        union { s16x4 v; uint2 u; } pb_;                                                                       \
+        pb_.u = make_uint2(pack_bf16x2(pr[0], pr[1]), pack_bf16x2(pr[2], pr[3]));                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+            /* rows past the last key are uninitialised memory: a NaN there would survive its zero weight */   \
+            const bool keep_ = !(LAST) || kv0 + 4 * lg + i < len;                                              \
+            *(uint4*)(vw + i * VROW) = keep_ ? vf[i].u : make_uint4(0u, 0u, 0u, 0u);                           \
         }                                                                                                      \
+        if (!(LAST)) DA_LOAD_V((T) + WAVES);                                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                 \
+        __builtin_amdgcn_wave_barrier();                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                 \
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   /* wave-uniform: the maximum rarely moves */   \
+            _Pragma("unroll") for (int dt = 0; dt < D / 16; ++dt) o[dt] *= alpha;                              \
+        }                                                                                                      \
+        _Pragma("unroll") for (int dt = 0; dt < D / 16; ++dt) {                                                \
+            const s16x4 va_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vr + 32 * dt)); \
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va_, pb_.v, o[dt], 0, 0, 0);                     \
+        }                                                                                                      \
+        __builtin_amdgcn_wave_barrier();                                                                       \
     }
     const int ntiles = (len + 15) >> 4;
-    Frag kfA[4], kfB[4];
-    uint32_t vvA[16], vvB[16];
+    Frag kf[4], vf[4];
     int t = wave;
-    if (t < ntiles) DA_LOAD(kfA, vvA, t);  // in flight while the queries are prepared
-    Frag qf[4];
+    if (t < ntiles) {   // in flight while the queries are prepared
+        DA_LOAD_K(t);
+        DA_LOAD_V(t);
+    }
     if constexpr (FUSED) {
         // One wave per head of this step's projections: GROUP query heads, then the key, then the value.
         const DecodeRopeIn& r = p.rope;
@@ -318,43 +348,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[ks].u = make_uint4(0, 0, 0, 0);
-            if (li < GROUP) qf[ks].u = *(const uint4*)(&sq[li][32 * ks + 8 * lg]);
-        }
     } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[ks].u = make_uint4(0, 0, 0, 0);
-            if (li < GROUP) qf[ks].u = *(const uint4*)(p.Q + (int64_t)row * p.q_ld + (kvh * GROUP + li) * D + 32 * ks + 8 * lg);
+        for (int idx = tid; idx < GROUP * D / 8; idx += 64 * WAVES) {
+            const int q = idx / (D / 8), ch = idx % (D / 8);
+            *(uint4*)(&sq[q][8 * ch]) = *(const uint4*)(p.Q + (int64_t)row * p.q_ld + (kvh * GROUP + q) * D + 8 * ch);
         }
+        __syncthreads();
     }
-    // Every tile that is consumed while another is in flight sits in a block whose loads are unconditional: the
-    // compiler counts outstanding loads per path and, where a load is conditional, waits as if it had not been
-    // issued, i.e. also for the tile that was just requested.  The last tile of a wave has its own copy of the code.
-    while (t < ntiles) {
-        const int t2 = t + WAVES;
-        if (t2 >= ntiles) {
-            DA_COMPUTE(kfA, vvA, t, true);
-            break;
-        }
-        DA_LOAD(kfB, vvB, t2);
-        DA_COMPUTE(kfA, vvA, t, false);   // a tile with a successor is full: no key of it lies past len
-        const int t3 = t2 + WAVES;
-        if (t3 >= ntiles) {
-            DA_COMPUTE(kfB, vvB, t2, true);
-            break;
-        }
-        DA_LOAD(kfA, vvA, t3);
-        DA_COMPUTE(kfB, vvB, t2, false);
-        t = t3;
+    // Every tile with a successor sits in a block whose loads are unconditional: the compiler counts outstanding loads
+    // per path and, where a load is conditional, waits as if it had not been issued, i.e. also for the rows that were
+    // just requested.  The last tile of a wave has its own copy of the code.
+    if (t < ntiles) {
+        for (; t + WAVES < ntiles; t += WAVES) DA_TILE(t, false);   // a tile with a successor is full: no key of it lies past len
+        DA_TILE(t, true);
     }
-#undef DA_LOAD
-#undef DA_COMPUTE
+#undef DA_LOAD_K
+#undef DA_LOAD_V
+#undef DA_TILE
     if constexpr (FUSED) {
         if (wave == 0) {  // the new key and value, from LDS: one more online-softmax step per query head
-            const float k0 = snew[0][2 * lane], k1 = snew[0][2 * lane + 1], v0 = snew[1][2 * lane], v1 = snew[1][2 * lane + 1];
+            const float k0 = snew[0][2 * lane], k1 = snew[0][2 * lane + 1];
 #pragma unroll
             for (int q = 0; q < GROUP; ++q) {
                 const uint32_t qq = *(const uint32_t*)(&sq[q][2 * lane]);
@@ -364,9 +377,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
                 const float m_new = fmaxf(mq, sc);
                 const float alpha = mq == -INFINITY ? 0.f : exp2f(mq - m_new);
                 const float pr = exp2f(sc - m_new);
-                o[q][0] = fmaf(pr, v0, o[q][0] * alpha);
-                o[q][1] = fmaf(pr, v1, o[q][1] * alpha);
-                if (li == q) { m = m_new; l = lq * alpha + pr; }
+                if (li == q) {   // the four lanes that hold this query's accumulators
+#pragma unroll
+                    for (int dt = 0; dt < D / 16; ++dt) {
+                        const f32x4 vn = *(const f32x4*)(&snew[1][16 * dt + 4 * lg]);
+                        o[dt] = o[dt] * alpha + pr * vn;
+                    }
+                    m = m_new;
+                    l = lq * alpha + pr;
+                }
             }
         }
     }
@@ -374,10 +393,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
         sm_m[wave][li] = m;
         sm_l[wave][li] = l;
     }
+    if (li < GROUP) {
 #pragma unroll
-    for (int q = 0; q < GROUP; ++q) {
-        so[wave][q][2 * lane] = o[q][0];
-        so[wave][q][2 * lane + 1] = o[q][1];
+        for (int dt = 0; dt < D / 16; ++dt) *(f32x4*)(&so[wave][li][16 * dt + 4 * lg]) = o[dt];
     }
     __syncthreads();
     for (int idx = tid; idx < GROUP * D; idx += 64 * WAVES) {
