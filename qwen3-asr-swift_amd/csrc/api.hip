@@ -160,7 +160,7 @@ int q3asr_decode_attention_cus(q3asr_model* m, int n_utt) {
     try {
         std::lock_guard<std::mutex> call_lock(m->call_mutex);
         HIP_CHECK(hipSetDevice(m->device));
-        return model_decode_att_cus(n_utt);
+        return model_decode_att_cus(m, n_utt);
     } catch (...) {
         return -1;
     }

@@ -176,4 +176,4 @@ void model_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t*
                   float* embeds_out, int64_t out_rows_capacity, int32_t* cu_tokens, int out_space);
 void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* res);
 int model_output_length(const q3asr_config& cfg, int frames);
-int model_decode_att_cus(int n_utt);
+int model_decode_att_cus(const q3asr_model* m, int n_utt);

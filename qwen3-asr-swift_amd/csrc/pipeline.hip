@@ -495,11 +495,15 @@ q3asr_model::DecodePlan decode_plan(Ctx& c, int rows, GemmWFmt wf, int cus, hipS
 }
 
 // Compute units the decode attention of a group of `b` utterances is confined to (0: one stream, the whole device for
-// every kernel).  Q3ASR_DECODE_ATT_CUS pins the share (tests, tuning).
-int decode_att_cus(int b) {
+// every kernel).  Q3ASR_DECODE_ATT_CUS pins the share (tests, tuning).  Measured at 2048 clips against one stream:
+// 1.7B bf16 -9 % decode time with 160 of 256 CUs (128: -3 %, 144: slower, the 256-wide projection tiles fill 96 CUs in
+// whole rounds), 0.6B bf16 -2.5 %, 0.6B 4-bit -4.6 %; the 1.7B 4-bit projections (dequantisation-bound) are too slow
+// on 96 CUs (+19 %) and take half of the device (-4 %).  Groups below 1024 utterances are faster on one stream.
+int decode_att_cus(const q3asr_model* m, int b) {
     const int cus_all = device_cus();
     const char* env_att = getenv("Q3ASR_DECODE_ATT_CUS");
-    int att_cus = (env_att ? atoi(env_att) : (b >= SPLIT_MIN_ROWS ? cus_all * 5 / 8 : 0)) & ~7;
+    const bool heavy_q4 = m->cfg.weight_format == 1 && m->cfg.hidden >= 2048;
+    int att_cus = (env_att ? atoi(env_att) : (b >= SPLIT_MIN_ROWS ? (heavy_q4 ? cus_all / 2 : cus_all * 5 / 8) : 0)) & ~7;
     if (b < 2 || cus_all % 8 != 0 || att_cus < 8 || cus_all - att_cus < 8) att_cus = 0;
     return att_cus;
 }
@@ -761,10 +765,8 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         // kernels of both run on a stream confined to `att_cus` CUs, everything else on a stream confined to the
         // remaining ones, chained by events so that one half's attention runs beside the other half's projections
         // (plain concurrent streams do not overlap them: each kernel fills every CU's registers on its own).
-        // The share is a fixed function of the group size (decode_att_cus): measured on the 1.7B model at 2048 clips,
-        // 160 + 96 CUs decode 9 % faster than one stream, 128 + 128 3 % faster, 144 + 112 slower (the 256-wide
-        // projection tiles fill 96 CUs in whole rounds); groups below 1024 utterances are faster on one stream.
-        const int att_cus = decode_att_cus(b);
+        // The share is a fixed function of the model and the group size (decode_att_cus).
+        const int att_cus = decode_att_cus(m, b);
         const int mm_cus = att_cus ? device_cus() - att_cus : 0;
         int n_half = att_cus ? 2 : 1;
         const bool was_split = n_half == 2;
@@ -1141,4 +1143,4 @@ void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* re
     }
 }
 
-int model_decode_att_cus(int n_utt) { return decode_att_cus(n_utt); }
+int model_decode_att_cus(const q3asr_model* m, int n_utt) { return decode_att_cus(m, n_utt); }
