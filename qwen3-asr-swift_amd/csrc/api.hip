@@ -74,8 +74,7 @@ void q3asr_destroy(q3asr_model* m) {
     m->arena.release();
     for (void* p : m->owned) (void)hipFree(p);
     for (hipEvent_t e : m->chain_events) (void)hipEventDestroy(e);
-    if (m->stream_att) (void)hipStreamDestroy(m->stream_att);
-    if (m->stream_mm) (void)hipStreamDestroy(m->stream_mm);
+    // (stream_att / stream_mm belong to the process-wide pair of their device and share: not destroyed here)
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

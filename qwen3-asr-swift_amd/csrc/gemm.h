@@ -36,6 +36,8 @@ struct GemmParams {
     float* part_val = nullptr;      // OUT_ARGMAX: [M][nparts]
     int* part_idx = nullptr;
     int nparts = 0;
+    int part_base = 0;              // OUT_ARGMAX over a column range of a wider matrix: first partial slot of this launch
+    int col_base = 0;               //   and the column index of W's first row in that matrix (added to the indices)
     int cus = 0;                    // compute units the launch stream may use (0: the whole device); sizes persistent grids
     int ksplit = 1;                 // OUT_SLAB: gridDim.z
     int64_t slab_stride = 0;

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const int c = c0 + b * 4 + r;
                     const float v = acc[a][b][r];
-                    if (c < p.N && v > best) { best = v; bidx = c; }
+                    if (c < p.N && v > best) { best = v; bidx = c + p.col_base; }
                 }
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
             }
             if (row_ok && lg == 0) {
-                const int part = tn * 2 + wc;
+                const int part = p.part_base + tn * 2 + wc;
                 p.part_val[(int64_t)m * p.nparts + part] = best;
                 p.part_idx[(int64_t)m * p.nparts + part] = bidx;
             }
@@ -448,12 +448,12 @@ void launch_gemm(const GemmParams& p, GemmAMode amode, GemmOut out, GemmWFmt wfm
     }
     if (tile == 3) {
         Q3_REQUIRE(can256, "gemm: the 256x256 tile needs plain rows and bf16 weights");
-        if (out == OUT_ARGMAX) Q3_REQUIRE(p.nparts == gemm_argmax_parts(p.N, 3), "gemm: nparts mismatch");
+        if (out == OUT_ARGMAX) Q3_REQUIRE(p.part_base + gemm_argmax_parts(p.N, 3) <= p.nparts, "gemm: nparts mismatch");
         launch_gemm256(p, out, s);
         return;
     }
     if (out == OUT_SWIGLU && tile == 1) tile = 2;
-    if (out == OUT_ARGMAX) Q3_REQUIRE(p.nparts == gemm_argmax_parts(p.N, tile == 2 ? 1 : tile), "gemm: nparts mismatch");
+    if (out == OUT_ARGMAX) Q3_REQUIRE(p.part_base + gemm_argmax_parts(p.N, tile == 2 ? 1 : tile) <= p.nparts, "gemm: nparts mismatch");
     if (amode == A_PLAIN) {
         if (wfmt == W_BF16) launch_out<A_PLAIN, W_BF16>(p, out, tile, s);
         else launch_out<A_PLAIN, W_Q4>(p, out, tile, s);

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 int bidx = 0x7fffffff;
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (c0 + e < p.N && v[e] > best) { best = v[e]; bidx = c0 + e; }
+                    if (c0 + e < p.N && v[e] > best) { best = v[e]; bidx = c0 + e + p.col_base; }
 #pragma unroll
                 for (int o = 16; o <= 32; o <<= 1) {
                     const float ov = __shfl_xor(best, o, 64);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
                 }
                 if (row_ok && lg == 0) {
-                    const int part = e_tn * 4 + wc;
+                    const int part = p.part_base + e_tn * 4 + wc;
                     p.part_val[(int64_t)m * p.nparts + part] = best;
                     p.part_idx[(int64_t)m * p.nparts + part] = bidx;
                 }

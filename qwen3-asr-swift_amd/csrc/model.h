@@ -155,7 +155,8 @@ struct q3asr_model {
     std::map<int, DecodePlan> decode_plans;   // measured plans (tuning runs), per row bucket
     std::set<int> plans_reported;             // buckets whose plan the verbose log has shown
     // Decode of a large group: the attention kernels run on a stream confined to `split_att_cus` compute units and
-    // every other kernel of the step on a stream confined to the remaining ones (created when first needed).
+    // every other kernel of the step on a stream confined to the remaining ones (the device's process-wide pair for
+    // that share, created when first needed and owned by the process, not by the model).
     hipStream_t stream_att = nullptr, stream_mm = nullptr;
     int split_att_cus = 0;
     std::vector<hipEvent_t> chain_events;    // ordering events between the two decode streams

@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <map>
+#include <mutex>
 #include <numeric>
 
 namespace {
@@ -511,16 +513,36 @@ int decode_att_cus(const q3asr_model* m, int b) {
 // Streams confined to complementary sets of compute units: mask bit i selects CU i / 8 of XCD i % 8, so the first
 // `att_cus` bits (a multiple of 8) take the same number of CUs from every XCD (a mask that leaves an XCD without a
 // CU is not accepted by the runtime).
+// Q3ASR_TRACE=1: the decode loop's host-side progress on stderr (where a stalled call stands)
+bool trace_on() {
+    static const bool on = [] { const char* e = getenv("Q3ASR_TRACE"); return e && atoi(e) != 0; }();
+    return on;
+}
+#define Q3_TRACE(...) do { if (trace_on()) { fprintf(stderr, "[q3asr] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
+// The two CU-confined streams of a device and share.  They are created once per process and never destroyed: a
+// queue with a CU mask that is destroyed and re-created under another mask while events still refer to its last
+// commands was followed by a call that never returned (seen once in a test that changes the share between calls).
+// Models on one device share them; their calls then simply queue behind one another on these streams.
 void ensure_split_streams(q3asr_model* m, int att_cus) {
     if (m->stream_att && m->split_att_cus == att_cus) return;
-    if (m->stream_att) { HIP_CHECK(hipStreamDestroy(m->stream_att)); m->stream_att = nullptr; }
-    if (m->stream_mm) { HIP_CHECK(hipStreamDestroy(m->stream_mm)); m->stream_mm = nullptr; }
-    const int cus = device_cus(), words = (cus + 31) / 32;
-    Q3_REQUIRE(cus % 8 == 0 && att_cus % 8 == 0 && att_cus >= 8 && cus - att_cus >= 8, "decode: bad compute-unit split");
-    std::vector<uint32_t> ma(words, 0), mb(words, 0);
-    for (int i = 0; i < cus; ++i) (i < att_cus ? ma : mb)[i >> 5] |= 1u << (i & 31);
-    HIP_CHECK(hipExtStreamCreateWithCUMask(&m->stream_att, (uint32_t)words, ma.data()));
-    HIP_CHECK(hipExtStreamCreateWithCUMask(&m->stream_mm, (uint32_t)words, mb.data()));
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::pair<hipStream_t, hipStream_t>> cache;   // (device, share) -> (attention, rest)
+    std::lock_guard<std::mutex> lk(mu);
+    auto& pair = cache[{m->device, att_cus}];
+    if (!pair.first) {
+        Q3_TRACE("split streams: creating the pair for %d attention CUs", att_cus);
+        const int cus = device_cus(), words = (cus + 31) / 32;
+        Q3_REQUIRE(cus % 8 == 0 && att_cus % 8 == 0 && att_cus >= 8 && cus - att_cus >= 8, "decode: bad compute-unit split");
+        std::vector<uint32_t> ma(words, 0), mb(words, 0);
+        for (int i = 0; i < cus; ++i) (i < att_cus ? ma : mb)[i >> 5] |= 1u << (i & 31);
+        hipStream_t sa = nullptr, sm = nullptr;
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&sa, (uint32_t)words, ma.data()));
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&sm, (uint32_t)words, mb.data()));
+        pair = {sa, sm};
+    }
+    m->stream_att = pair.first;
+    m->stream_mm = pair.second;
     m->split_att_cus = att_cus;
 }
 
@@ -866,14 +888,16 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             return x.plan.ks[which];
         };
         // per half and layer: "q/k/v rows ready" and "attention done" events between the two streams
-        if ((int)m->chain_events.size() < 4 * cfg.layers + 2) {
+        if ((int)m->chain_events.size() < 4 * cfg.layers + 6) {
             const size_t old = m->chain_events.size();
-            m->chain_events.resize(4 * cfg.layers + 2);
+            m->chain_events.resize(4 * cfg.layers + 6);
             for (size_t i = old; i < m->chain_events.size(); ++i) HIP_CHECK(hipEventCreateWithFlags(&m->chain_events[i], hipEventDisableTiming));
         }
         hipEvent_t* ev_pre[2] = {m->chain_events.data(), m->chain_events.data() + cfg.layers};
         hipEvent_t* ev_attn[2] = {m->chain_events.data() + 2 * cfg.layers, m->chain_events.data() + 3 * cfg.layers};
         hipEvent_t ev_fork = m->chain_events[4 * cfg.layers], ev_join = m->chain_events[4 * cfg.layers + 1];
+        hipEvent_t* ev_xlast = m->chain_events.data() + 4 * cfg.layers + 2;   // per half: final-norm rows ready for the LM head
+        hipEvent_t* ev_lm = m->chain_events.data() + 4 * cfg.layers + 4;      // per half: the attention stream's share of the LM head done
         int active = b;
         HIP_CHECK(hipMemcpyAsync(&active, st_active, 4, hipMemcpyDeviceToHost, c.s));
         HIP_CHECK(hipStreamSynchronize(c.s));
@@ -988,6 +1012,75 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             step(1, x.r0, x.rows, x.active_dev, st_map[x.cur] + x.r0, st_map[x.cur ^ 1] + x.r0, x.keys + it + 1, x.s);
             res->decode_rows += x.rows;
         };
+        // The LM head is the one long kernel of a step (vocabulary x hidden against every row), and with two halves it is
+        // the stretch during which the attention stream runs dry: a half's next attention needs that half's next token.
+        // So at the end of a step both streams share it: the attention stream's CUs take the first `ta` 256-column tiles
+        // of the vocabulary for both halves, the other stream the rest, each writing its own range of the per-row
+        // (max, index) partials; one reduction per half then picks the token (lowest index on ties, as before: every
+        // logit is the same sum whichever stream computes it).  `ta` balances the two streams in tile rounds, the
+        // attention stream starting `lm_lead` rounds early (it idles while the last layer's `post` runs).
+        const char* env_lms = getenv("Q3ASR_LM_SPLIT");
+        const char* env_lead = getenv("Q3ASR_LM_SPLIT_LEAD");
+        // Q3ASR_LM_SPLIT=0: every half's LM head whole on the projections' stream; 2: shared also where the 256x256 tile
+        // would not be the LM head's own choice (small test groups)
+        const bool lm_split_on = !(env_lms && atoi(env_lms) == 0) && was_split && wf == W_BF16 && !logits;
+        const bool lm_split_any = env_lms && atoi(env_lms) == 2;
+        const int lm_lead = env_lead ? atoi(env_lead) : 7;
+        auto lm_split_ok = [&]() {
+            return lm_split_on && chain && n_half == 2 && hv[0].rows > 0 && hv[1].rows > 0 && !hv[0].gemv && !hv[1].gemv &&
+                   (lm_split_any || (head_tile_for(hv[0].rows) == 3 && head_tile_for(hv[1].rows) == 3));
+        };
+        auto lm_split_tiles = [&]() {
+            const int tn = cdiv(cfg.vocab, 256), ga = std::max(8, att_cus & ~7), gb = std::max(8, mm_cus & ~7);
+            const int t0 = cdiv(hv[0].rows, 256), t1 = cdiv(hv[1].rows, 256);
+            int best = 0;
+            long best_cost = -1;
+            for (int ta = 0; ta < tn; ++ta) {   // the other stream keeps at least the last (partial) tile
+                const long ca = cdiv(t0 * ta, ga) + cdiv(t1 * ta, ga);
+                const long cb = lm_lead + cdiv(t0 * (tn - ta), gb) + cdiv(t1 * (tn - ta), gb);
+                const long cost = std::max(ca, cb);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ta; }
+            }
+            return best;
+        };
+        const int lm_nparts = gemm_argmax_parts(cfg.vocab, 3);
+        auto lm_part = [&](int h, int col0, int ncols, hipStream_t s, int cus) {
+            Half& x = hv[h];
+            GemmParams p = gp(c, x.x_last, H, m->embed, x.rows);
+            p.W = (const bf16_t*)m->embed.w + (size_t)col0 * H;
+            p.N = ncols; p.col_base = col0; p.part_base = col0 / 256 * 4; p.cus = cus;
+            p.part_val = part_val + (size_t)x.r0 * max_parts; p.part_idx = part_idx + (size_t)x.r0 * max_parts; p.nparts = lm_nparts;
+            launch_gemm(p, A_PLAIN, OUT_ARGMAX, wf, 3, s);
+        };
+        // last layer's post, final norm, shared LM head, bookkeeping and the next step's first `pre` of both halves
+        auto tail_split = [&](int it, bool more) {
+            const int l = cfg.layers - 1;
+            const int ta = lm_split_tiles();
+            for (int h = 0; h < 2; ++h) {
+                Half& x = hv[h];
+                post(h, l);
+                launch_rmsnorm(x.hid, m->final_norm, x.x_last, x.rows, H, cfg.rms_eps, nullptr, x.slab, pend_down[h], (int64_t)x.rows * H, x.s);
+                if (ta > 0) HIP_CHECK(hipEventRecord(ev_xlast[h], x.s));
+            }
+            if (ta > 0)
+                for (int h = 0; h < 2; ++h) {
+                    Half& x = hv[h];
+                    HIP_CHECK(hipStreamWaitEvent(x.sa, ev_xlast[h], 0));
+                    if (prof_active(x.sa)) launch_noop(x.sa);   // keeps a timed launch's start event behind the wait
+                    lm_part(h, 0, ta * 256, x.sa, att_cus);
+                    HIP_CHECK(hipEventRecord(ev_lm[h], x.sa));
+                }
+            for (int h = 0; h < 2; ++h) lm_part(h, ta * 256, cfg.vocab - ta * 256, hv[h].s, mm_cus);
+            for (int h = 0; h < 2; ++h) {
+                Half& x = hv[h];
+                if (ta > 0) HIP_CHECK(hipStreamWaitEvent(x.s, ev_lm[h], 0));
+                launch_argmax_reduce(part_val + (size_t)x.r0 * max_parts, part_idx + (size_t)x.r0 * max_parts, lm_nparts, x.rows, st_argmax + x.r0, x.s);
+                step(1, x.r0, x.rows, x.active_dev, st_map[x.cur] + x.r0, st_map[x.cur ^ 1] + x.r0, x.keys + it + 1, x.s);
+                res->decode_rows += x.rows;
+                x.pre_issued = more;
+                if (more) pre(h, 0);
+            }
+        };
         // With two halves the attention stream runs A(0,l) A(1,l) A(0,l+1) ... and the other stream post(0,l) pre(0,l+1)
         // post(1,l) pre(1,l+1) ...: while one half's attention streams the cache, the other half's projections run.
         // A half's first `pre` of the next step follows its bookkeeping at once (`more`: another step will be issued),
@@ -998,6 +1091,10 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             for (int l = 0; l < cfg.layers; ++l) {
                 for (int h = 0; h < n_half; ++h)
                     if (hv[h].rows > 0) attn(h, l, it);
+                if (l + 1 == cfg.layers && lm_split_ok()) {
+                    tail_split(it, more);
+                    break;
+                }
                 for (int h = 0; h < n_half; ++h) {
                     if (hv[h].rows == 0) continue;
                     post(h, l);
@@ -1017,16 +1114,19 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         // utterance is bound by streaming the 3.4 GB of weights per step, not by the host's launch rate.)
         const char* env_merge = getenv("Q3ASR_DECODE_MERGE_ROWS");
         const int merge_rows = std::min(env_merge ? atoi(env_merge) : SPLIT_MERGE_ROWS, hv[0].n);
+        Q3_TRACE("decode: %d utterances, %d halves, attention CUs %d, shared LM head %d", b, n_half, att_cus, (int)lm_split_ok());
         for (int it = 1; it < max_tokens && active > 0; ++it) {
             const bool poll = it % POLL_STEPS == 0 || it + 1 == max_tokens;
             issue_step(it, it + 1 < max_tokens);
             res->decode_steps += 1;
             if (!poll) continue;
+            Q3_TRACE("step %d issued, waiting (rows %d + %d)", it, hv[0].rows, n_half == 2 ? hv[1].rows : 0);
             int act_h[2] = {0, 0};
             for (int h = 0; h < n_half; ++h)
                 if (hv[h].rows > 0) HIP_CHECK(hipMemcpyAsync(&act_h[h], hv[h].active_dev, 4, hipMemcpyDeviceToHost, hv[h].s));
             for (int h = 0; h < n_half; ++h) HIP_CHECK(hipStreamSynchronize(hv[h].s));   // (the attention stream has drained before the bookkeeping ran)
             active = act_h[0] + act_h[1];
+            Q3_TRACE("step %d done, %d utterances running", it, active);
             if (!retire || active == 0) continue;
             for (int h = 0; h < n_half; ++h) {
                 Half& x = hv[h];

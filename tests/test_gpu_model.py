@@ -175,11 +175,50 @@ def test_split_decode_equals_one_stream(pinned_model, monkeypatch):
         two = m.transcribe_batch(audios, 16000, max_tokens=24)
         assert one.tokens == two.tokens, att_cus
         assert one.decode_steps == two.decode_steps
+    # the step's LM head shared between the two streams by vocabulary range (forced here: a group this small would
+    # keep it on one stream), with the cut at the default place, at the far end and with nothing on the attention stream
+    monkeypatch.setenv("Q3ASR_LM_SPLIT", "2")
+    for lead in (None, "-4000", "4000"):
+        if lead is not None:
+            monkeypatch.setenv("Q3ASR_LM_SPLIT_LEAD", lead)
+        two = m.transcribe_batch(audios, 16000, max_tokens=24)
+        assert one.tokens == two.tokens, lead
+    monkeypatch.delenv("Q3ASR_LM_SPLIT_LEAD")
+    monkeypatch.setenv("Q3ASR_LM_SPLIT", "0")
+    two = m.transcribe_batch(audios, 16000, max_tokens=24)
+    assert one.tokens == two.tokens
+    monkeypatch.delenv("Q3ASR_LM_SPLIT")
     forced = np.tile(np.arange(100, 110, dtype=np.int32), (5, 1))
     a = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
     monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "0")
     b = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
     assert _rel(a.taps["logits"], b.taps["logits"]) <= 1e-3
+
+
+def test_large_group_takes_the_split_decode_by_itself(monkeypatch):
+    """1100 short clips in one group: the library's own choices apply (two halves, attention on its share of the
+    compute units, 256x256 LM head shared between the two streams by vocabulary range) and must give, clip by clip,
+    the free-running tokens of the one-stream decode.  Projections pinned to one summation order as in pinned_model."""
+    for k, v in (("Q3ASR_DECODE_TILE", "1"), ("Q3ASR_DECODE_SPLIT", "1"), ("Q3ASR_DECODE_NO_FUSE", "1"), ("Q3ASR_DECODE_GEMV", "0")):
+        monkeypatch.setenv(k, v)
+    cfg = make_config("tiny", max_batch=1100)
+    ck = synth.make_checkpoint(cfg, seed=1)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck, device=0)
+    try:
+        base = [synth.synth_audio(9600 + 800 * i, 300 + i) for i in range(11)]
+        audios = [base[i % 11] for i in range(1100)]
+        monkeypatch.delenv("Q3ASR_DECODE_ATT_CUS", raising=False)
+        assert m.decode_attention_cus(1100) > 0
+        two = m.transcribe_batch(audios, 16000, max_tokens=12)
+        monkeypatch.setenv("Q3ASR_LM_SPLIT", "0")
+        whole_head = m.transcribe_batch(audios, 16000, max_tokens=12)
+        monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "0")
+        one = m.transcribe_batch(audios, 16000, max_tokens=12)
+        assert two.tokens == one.tokens and whole_head.tokens == one.tokens
+        for i in range(11, 1100):                       # the same clip in another slot (and the other half)
+            assert two.tokens[i] == two.tokens[i % 11]
+    finally:
+        m.close()
 
 
 @pytest.mark.parametrize("variant", ["default", "rotate_half"])

@@ -121,8 +121,8 @@ def test_free_running_stops_retire_too(pinned_model, monkeypatch):
     assert drop.decode_rows <= keep.decode_rows
 
 
-@pytest.mark.parametrize("merge_rows", [0, 4, 100])
-def test_split_decode_retires_and_merges(pinned_model, monkeypatch, merge_rows):
+@pytest.mark.parametrize("merge_rows,lm_split", [(0, "1"), (4, "2"), (100, "1"), (0, "2")])
+def test_split_decode_retires_and_merges(pinned_model, monkeypatch, merge_rows, lm_split):
     """The two-half decode (attention on its own share of the compute units) drops finished rows per half and goes
     back to one list on one stream when few utterances are left (merge_rows) or a half has emptied (here: half 0
     holds only early stops): the tokens are those of the single-stream run that keeps every row."""
@@ -139,6 +139,7 @@ def test_split_decode_retires_and_merges(pinned_model, monkeypatch, merge_rows):
     monkeypatch.setenv("Q3ASR_RETIRE", "1")
     monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "160")
     monkeypatch.setenv("Q3ASR_DECODE_MERGE_ROWS", str(merge_rows))
+    monkeypatch.setenv("Q3ASR_LM_SPLIT", lm_split)   # 2: the LM head shared between the two streams even for this small group
     split = m.transcribe_batch(audios, 16000, max_tokens=max_tokens, forced_tokens=forced, stop_rules="forced")
     assert split.tokens == keep.tokens
     assert split.decode_steps == max_tokens - 1
