@@ -355,13 +355,14 @@ def main():
             "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
                          "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:16]],
         }
+        model.close()
+        del dev_audio
         if world == 1 and not args.no_cpu_baseline and args.workload == "transcribe" and args.weights == "bf16":
-            model.close()
-            del dev_audio
             line["cpu_baseline"] = cpu_baseline(cfg, ck, clips[0], args.cpu_decode_steps)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+    model.close()          # streams and events are released before the process (and any profiler around it) winds down
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -74,7 +74,10 @@ void q3asr_destroy(q3asr_model* m) {
     m->arena.release();
     for (void* p : m->owned) (void)hipFree(p);
     for (hipEvent_t e : m->chain_events) (void)hipEventDestroy(e);
-    // (stream_att / stream_mm belong to the process-wide pair of their device and share: not destroyed here)
+    for (auto& kv : m->split_streams) {
+        if (kv.second.first) (void)hipStreamDestroy(kv.second.first);
+        if (kv.second.second) (void)hipStreamDestroy(kv.second.second);
+    }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

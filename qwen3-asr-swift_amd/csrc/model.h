@@ -155,10 +155,11 @@ struct q3asr_model {
     std::map<int, DecodePlan> decode_plans;   // measured plans (tuning runs), per row bucket
     std::set<int> plans_reported;             // buckets whose plan the verbose log has shown
     // Decode of a large group: the attention kernels run on a stream confined to `split_att_cus` compute units and
-    // every other kernel of the step on a stream confined to the remaining ones (the device's process-wide pair for
-    // that share, created when first needed and owned by the process, not by the model).
+    // every other kernel of the step on a stream confined to the remaining ones (created when first needed; a pair
+    // per share that has been asked for, all kept until the model is destroyed).
     hipStream_t stream_att = nullptr, stream_mm = nullptr;
     int split_att_cus = 0;
+    std::map<int, std::pair<hipStream_t, hipStream_t>> split_streams;   // attention CUs -> (attention stream, other stream)
     std::vector<hipEvent_t> chain_events;    // ordering events between the two decode streams
 
     template <class T>

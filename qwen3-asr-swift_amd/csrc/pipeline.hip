@@ -12,8 +12,6 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
-#include <map>
-#include <mutex>
 #include <numeric>
 
 namespace {
@@ -21,7 +19,7 @@ namespace {
 constexpr int TOK_IM_START = 151644, TOK_IM_END = 151645, TOK_AUDIO_START = 151669, TOK_AUDIO_END = 151670;
 constexpr int TOK_AUDIO_PAD = 151676, TOK_ASR_TEXT = 151704, TOK_NEWLINE = 198, TOK_SYSTEM = 8948, TOK_USER = 872;
 constexpr int TOK_ASSISTANT = 77091;
-constexpr int ENC_CHUNK_BUDGET = 3840;  // chunks per encoder pass (128 clips of 30 s; conv1's output is 3 MB per chunk;
+constexpr int ENC_CHUNK_BUDGET = 5120;  // most chunks per encoder pass (170 clips of 30 s; conv1's output is 3 MB per chunk;
                                         // measured: 960 -> 673 ms, 3840 -> 590 ms, 7680 -> 581 ms per 1024 clips)
 constexpr int POLL_STEPS = 8;
 constexpr int SPLIT_MIN_ROWS = 1024;    // groups from this size on decode as two halves on disjoint sets of compute units
@@ -148,6 +146,26 @@ std::vector<int> run_encoder(Ctx& c, const float* mel, int t_stride, const unsig
             if (u1 > u0 && nch + k > ENC_CHUNK_BUDGET) break;
             nch += k;
             ++u1;
+        }
+        // The layers' narrow linears (N = d_model) run one 256 x 256 tile per compute unit per round, and with only
+        // d_model / 256 column tiles a pass of 170 clips leaves most of its last round empty (1036 tiles: a fifth round
+        // for 12).  When more utterances follow, the pass gives up to an eighth of its utterances to the next one if
+        // the rounds it then runs are fuller (168 clips of 30 s: 65 520 rows = 256 row tiles, four full rounds).
+        if (u1 < b) {
+            const int cus = device_cus(), tiles_n = cdiv(d, 256);
+            std::vector<int64_t> rows_upto(u1 - u0 + 1, 0);
+            for (int u = u0; u < u1; ++u) rows_upto[u - u0 + 1] = rows_upto[u - u0] + ntok[u];
+            auto fill = [&](int64_t rows) {
+                const int64_t rounds = cdiv((int64_t)cdiv(rows, 256) * tiles_n, cus);
+                return (double)rows * d / ((double)rounds * cus * 65536.0);
+            };
+            int best = u1;
+            double best_fill = fill(rows_upto[u1 - u0]);
+            for (int e = u1 - 1; e > u0 && e >= u1 - (u1 - u0) / 8; --e) {
+                const double f = fill(rows_upto[e - u0]);
+                if (f > best_fill + 0.03) { best_fill = f; best = e; }
+            }
+            u1 = best;
         }
         const auto mark = m->arena.mark();
         std::vector<int> ch_utt, ch_t0, ch_len, win1, win2, rowmap3, rowmap_tok;
@@ -520,16 +538,13 @@ bool trace_on() {
 }
 #define Q3_TRACE(...) do { if (trace_on()) { fprintf(stderr, "[q3asr] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
-// The two CU-confined streams of a device and share.  They are created once per process and never destroyed: a
-// queue with a CU mask that is destroyed and re-created under another mask while events still refer to its last
-// commands was followed by a call that never returned (seen once in a test that changes the share between calls).
-// Models on one device share them; their calls then simply queue behind one another on these streams.
+// The two CU-confined streams for a share of the device.  A model keeps every pair it has created until it is
+// destroyed: a queue with a CU mask that is destroyed and re-created under another mask while the model's ordering
+// events still refer to its last commands was followed by a call that never returned (seen once in a test that
+// changes the share between calls).
 void ensure_split_streams(q3asr_model* m, int att_cus) {
     if (m->stream_att && m->split_att_cus == att_cus) return;
-    static std::mutex mu;
-    static std::map<std::pair<int, int>, std::pair<hipStream_t, hipStream_t>> cache;   // (device, share) -> (attention, rest)
-    std::lock_guard<std::mutex> lk(mu);
-    auto& pair = cache[{m->device, att_cus}];
+    auto& pair = m->split_streams[att_cus];
     if (!pair.first) {
         Q3_TRACE("split streams: creating the pair for %d attention CUs", att_cus);
         const int cus = device_cus(), words = (cus + 31) / 32;

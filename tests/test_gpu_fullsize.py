@@ -1,5 +1,5 @@
-"""The benchmark configurations at their own size: 0.6B bf16 x 128 clips of 30 s, 0.6B MLX-q4 x 256 clips, and a
-1.7B slice of 5-300 s recordings cut into pieces.  The CPU restatement cannot cover these in seconds, so each run is
+"""The benchmark configurations at their own size: 0.6B bf16 x 128 clips of 30 s, 0.6B MLX-q4 x 256 clips, a
+1.7B slice of 5-300 s recordings cut into pieces, and the headline's 2048 clips of 30 s through the 1.7B model.  The CPU restatement cannot cover these in seconds, so each run is
 checked through properties (audio-token counts by the reference's length algebra, AudioEncoder.swift:254-270; a
 clip's tokens do not depend on its slot or on its neighbours; finite logits), three utterances are checked against
 their own single-utterance runs under one pinned kernel variant, and one utterance's first-step logits are checked
@@ -103,5 +103,39 @@ def test_17b_ragged_recordings_in_pieces(monkeypatch):
         for u in (0, 5, n_half - 1):
             alone = m.transcribe_batch([pieces[u]], 16000, max_tokens=steps, stop_rules=False)
             assert alone.tokens[0] == pinned.tokens[u], u
+    finally:
+        m.close()
+
+
+def test_17b_2048_clips_of_30s_split_decode(monkeypatch):
+    """The headline configuration at its own size: 2048 clips of 30 s through the 1.7B model, decoded as two halves
+    on CU-confined streams with the LM head shared between them.  A clip's tokens do not depend on its half or slot,
+    keeping each half's LM head whole changes nothing, and under one pinned projection variant the two-half decode
+    gives the one-stream tokens."""
+    cfg = make_config("1.7b", max_batch=2048)
+    ck = synth.make_checkpoint(cfg, seed=0)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        base = [synth.synth_audio(480000, 2000 + i, "noise" if i % 8 == 7 else "speechlike") for i in range(64)]
+        clips = [base[i % 64] for i in range(2048)]
+        steps = 6
+        monkeypatch.delenv("Q3ASR_DECODE_ATT_CUS", raising=False)
+        monkeypatch.delenv("Q3ASR_LM_SPLIT", raising=False)
+        assert m.decode_attention_cus(2048) == 160
+        out = m.transcribe_batch(clips, 16000, max_tokens=steps, stop_rules=False)
+        assert (np.asarray(out.n_audio_tokens) == 390).all()
+        assert all(len(t) == steps and all(0 <= x < cfg.vocab for x in t) for t in out.tokens)
+        for i in range(64, 2048):
+            assert out.tokens[i] == out.tokens[i % 64], i          # same clip, other slot or other half: same tokens
+        monkeypatch.setenv("Q3ASR_LM_SPLIT", "0")
+        whole_head = m.transcribe_batch(clips, 16000, max_tokens=steps, stop_rules=False)
+        assert whole_head.tokens == out.tokens
+        monkeypatch.delenv("Q3ASR_LM_SPLIT")
+        for k, v in PINS:
+            monkeypatch.setenv(k, v)
+        two = m.transcribe_batch(clips, 16000, max_tokens=steps, stop_rules=False)
+        monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "0")
+        one = m.transcribe_batch(clips, 16000, max_tokens=steps, stop_rules=False)
+        assert two.tokens == one.tokens
     finally:
         m.close()
