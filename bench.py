@@ -83,7 +83,12 @@ def pmc_traffic(kernel, args):
             or args.workload == "ragged" or args.audio != "speechlike" or args.length_dist != "none"):
         return None, None
     short = kernel.split("<")[0].replace("_kernel", "")
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{short}_b{args.batch}.json")), reverse=True):
+    # the passes exist for the library's own decode (two halves per launch pair) and for one stream (Q3ASR_DECODE_ATT_CUS=0)
+    share = os.environ.get("Q3ASR_DECODE_ATT_CUS")
+    if share not in (None, "0"):
+        return None, None
+    suffix = "_one_stream" if share == "0" and short == "decode_attn" else ""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{short}_b{args.batch}{suffix}.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
         return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
