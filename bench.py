@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with one GPU, together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--rehearse-collectives", action="store_true", help="one rank only: open a process group of one rank on "
+                    "--backend anyway and run the job's exchange (all_gather of token lists, all_reduce of counters, barriers) "
+                    "through it -- the RCCL calls of a multi-GPU run, on a box with one GPU")
     ap.add_argument("--workload", default="transcribe", choices=["transcribe", "mel", "ragged"],
                     help="transcribe: the headline run, --batch clips of --clip-seconds per GPU.  mel: the log-mel frontend alone on the "
                          "same clips (device buffers in and out).  ragged: --utterances recordings per GPU with durations U[5, 300] s "
@@ -204,8 +207,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: libq3asr has no CPU path")
     torch.cuda.set_device(local_rank)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the collectives' tensors live
-    if world > 1:
+    group = world > 1 or args.rehearse_collectives       # a process group exists and the exchange runs through it
+    if group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -265,17 +273,17 @@ def main():
             return out
         out = model.transcribe_batch(None, 16000, max_tokens=args.max_tokens, device_audio=(dev_audio.data_ptr(), offsets),
                                      stop_rules="forced" if forced is not None else not args.no_stop_rules, forced_tokens=forced)
-        if world > 1:
+        if group:
             # the job's one exchange: every rank ends the batch holding every transcript (token ids)
             from q3asr.shard import gather_token_lists
             local = dict(zip(piece_ids, out.tokens))
-            everything = gather_token_lists(local, n_units_total, dist, device=coll_dev)
-            assert len(everything) == n_units_total
+            everything = gather_token_lists(local, n_units_total, dist, device=coll_dev, always=True)
+            assert len(everything) == n_units_total and all(everything[i] == t for i, t in local.items())
         return out
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -294,7 +302,7 @@ def main():
     tokens = sum(o.tokens_total for o in outs)
     row_steps = sum(getattr(o, "decode_rows", 0) for o in outs)
     stats = torch.tensor([dt, audio_s, float(tokens), float(row_steps)], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if group:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -368,7 +376,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     model.close()          # streams and events are released before the process (and any profiler around it) winds down
-    if world > 1:
+    if group:
         dist.barrier()
         dist.destroy_process_group()
 

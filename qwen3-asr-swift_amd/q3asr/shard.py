@@ -31,11 +31,12 @@ def shard_utterances(lengths_16k, world, max_tokens=448, costs=None):
     return shards
 
 
-def gather_token_lists(local, n_total, dist=None, device="cpu"):
+def gather_token_lists(local, n_total, dist=None, device="cpu", always=False):
     """local: dict utterance index -> list of token ids held by this rank.  Returns the full list of
-    n_total token lists on every rank (all_gather of counts, then of one padded int32 buffer)."""
+    n_total token lists on every rank (all_gather of counts, then of one padded int32 buffer).
+    always: run the collectives even in a group of one rank (rehearsal of the exchange on a single GPU)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return [local.get(i, []) for i in range(n_total)]
     world = dist.get_world_size()
     idx = sorted(local)

@@ -5,6 +5,7 @@ import json
 import os
 import re
 import struct
+import sys
 
 import numpy as np
 import pytest
@@ -288,3 +289,42 @@ def test_config_json_fields_the_reference_reads():
     assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert all(1600 <= e - s <= 480000 for s, e in spans)
     assert len(split_points(np.zeros(480000, np.float32), 16000)) == 1
+
+
+def test_bench_traffic_figure_follows_the_decode_mode(monkeypatch):
+    """bench.py's roofline.traffic comes from committed counter passes: the default run (two halves per launch pair)
+    and the one-stream run (Q3ASR_DECODE_ATT_CUS=0) each have their own summary, any other share or workload has none."""
+    import argparse
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = argparse.Namespace(preset="1.7b", max_tokens=448, clip_seconds=30.0, weights="bf16", workload="transcribe",
+                              audio="speechlike", length_dist="none", batch=2048)
+    monkeypatch.delenv("Q3ASR_DECODE_ATT_CUS", raising=False)
+    split_bytes, split_src = bench.pmc_traffic("decode_attn_kernel", args)
+    monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "0")
+    one_bytes, one_src = bench.pmc_traffic("decode_attn_kernel", args)
+    assert split_src.endswith("_pmc_decode_attn_b2048.json") and one_src.endswith("_pmc_decode_attn_b2048_one_stream.json")
+    assert 1.9 < one_bytes / split_bytes < 2.1           # one launch covers the whole group instead of a half
+    monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "176")
+    assert bench.pmc_traffic("decode_attn_kernel", args) == (None, None)
+    monkeypatch.delenv("Q3ASR_DECODE_ATT_CUS")
+    args.max_tokens = 96
+    assert bench.pmc_traffic("decode_attn_kernel", args) == (None, None)
+
+
+def test_kernel_stats_summary_from_a_trace(tmp_path):
+    """scripts/kernel_stats.py: per-kernel calls / total / average from a rocprofv3 kernel trace."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "prof" / "host" / "1"
+    d.mkdir(parents=True)
+    rows = ["Kind,Agent_Id,Queue_Id,Kernel_Name,Start_Timestamp,End_Timestamp",
+            "KERNEL_DISPATCH,1,1,kern_a,1000,3000", "KERNEL_DISPATCH,1,2,kern_b,1500,2000", "KERNEL_DISPATCH,1,1,kern_a,4000,8000"]
+    (d / "t_kernel_trace.csv").write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "kernel_stats.py"), str(tmp_path / "prof")],
+                         check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert out[0] == "Name,Calls,TotalDurationUs,AverageUs,Percentage"
+    assert out[1].startswith("kern_a,2,6.0,3.0,") and out[2].startswith("kern_b,1,0.5,0.5,")
