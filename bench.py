@@ -196,6 +196,14 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries the one JSON line and nothing else: whatever libraries print there (RCCL announces its version on
+    # stdout when a process group starts) goes to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+
     import torch
     import torch.distributed as dist
     from q3asr import Qwen3ASRModel, make_config, synth
@@ -327,13 +335,13 @@ def main():
                  f"rules, max_tokens {args.max_tokens}), {what}, audio resident in HBM, seeded random weights of the true shapes; {lengths}")
     if rank == 0 and not prof:
         ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
-        print(json.dumps({"metric": metric, "value": round(audio_s / dt, 2),
+        emit({"metric": metric, "value": round(audio_s / dt, 2),
                           "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32" if args.workload == "mel" else "bf16", "data": "synthetic",
                           "config": {"workload": "run without kernel timing: " + label, "clips_per_gpu": n_local,
                                      "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}},
-                          "roofline": None, "cpu_baseline": None}), flush=True)
+                          "roofline": None, "cpu_baseline": None})
     elif rank == 0:
         # dominant kernel by device time (sampled HIP-event timings scaled to all launches)
         for p in prof:
@@ -374,7 +382,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, ck, clips[0], args.cpu_decode_steps)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        emit(line)
     model.close()          # streams and events are released before the process (and any profiler around it) winds down
     if group:
         dist.barrier()

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "qwen3-asr-swift_amd"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the library's decode loop reports its host-side progress on stderr: pytest shows it only for a test that fails or
+# times out, which is where one wants to know at which step a call stood
+os.environ.setdefault("Q3ASR_TRACE", "1")
 
 
 def pytest_configure(config):
