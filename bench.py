@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "qwen3-asr-swift_amd"))
 
+T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
@@ -295,13 +296,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    last_note = [T_START]
+
+    def note(what):
+        # a line on stderr at most every 20 s: a long run shows that it is alive (stdout stays reserved for the result)
+        now = time.perf_counter()
+        if rank == 0 and now - last_note[0] >= 20.0:
+            last_note[0] = now
+            print(f"[bench] {what}", file=sys.stderr, flush=True)
+
+    note("weights and audio resident, starting the warmup steps")
+    for i in range(args.warmup):
         step()
+        note(f"warmup step {i + 1} of {args.warmup} done")
     if not args.no_profile:
         model.profile_start(args.profile_stride)
     fence()
     t0 = time.perf_counter()
-    outs = [step() for _ in range(args.steps)]
+    outs = []
+    for i in range(args.steps):
+        outs.append(step())
+        note(f"timed step {i + 1} of {args.steps} issued and returned")
     fence()
     dt = time.perf_counter() - t0
     prof = [] if args.no_profile else model.profile_stop()
