@@ -74,10 +74,9 @@ void q3asr_destroy(q3asr_model* m) {
     m->arena.release();
     for (void* p : m->owned) (void)hipFree(p);
     for (hipEvent_t e : m->chain_events) (void)hipEventDestroy(e);
-    for (auto& kv : m->split_streams) {
-        if (kv.second.first) (void)hipStreamDestroy(kv.second.first);
-        if (kv.second.second) (void)hipStreamDestroy(kv.second.second);
-    }
+    for (auto& kv : m->split_streams)
+        for (hipStream_t s : {kv.second.att, kv.second.att2, kv.second.mm})
+            if (s) (void)hipStreamDestroy(s);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

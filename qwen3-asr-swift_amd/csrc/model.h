@@ -158,8 +158,10 @@ struct q3asr_model {
     // every other kernel of the step on a stream confined to the remaining ones (created when first needed; a pair
     // per share that has been asked for, all kept until the model is destroyed).
     hipStream_t stream_att = nullptr, stream_mm = nullptr;
+    hipStream_t stream_att2 = nullptr;       // second stream on the attention's CUs (the second half's attention launches)
     int split_att_cus = 0;
-    std::map<int, std::pair<hipStream_t, hipStream_t>> split_streams;   // attention CUs -> (attention stream, other stream)
+    struct SplitStreams { hipStream_t att = nullptr, mm = nullptr, att2 = nullptr; };
+    std::map<int, SplitStreams> split_streams;   // attention CUs -> the streams confined to that share and to the rest
     std::vector<hipEvent_t> chain_events;    // ordering events between the two decode streams
 
     template <class T>

@@ -544,20 +544,20 @@ bool trace_on() {
 // changes the share between calls).
 void ensure_split_streams(q3asr_model* m, int att_cus) {
     if (m->stream_att && m->split_att_cus == att_cus) return;
-    auto& pair = m->split_streams[att_cus];
-    if (!pair.first) {
-        Q3_TRACE("split streams: creating the pair for %d attention CUs", att_cus);
+    auto& st = m->split_streams[att_cus];
+    if (!st.att) {
+        Q3_TRACE("split streams: creating the streams for %d attention CUs", att_cus);
         const int cus = device_cus(), words = (cus + 31) / 32;
         Q3_REQUIRE(cus % 8 == 0 && att_cus % 8 == 0 && att_cus >= 8 && cus - att_cus >= 8, "decode: bad compute-unit split");
         std::vector<uint32_t> ma(words, 0), mb(words, 0);
         for (int i = 0; i < cus; ++i) (i < att_cus ? ma : mb)[i >> 5] |= 1u << (i & 31);
-        hipStream_t sa = nullptr, sm = nullptr;
-        HIP_CHECK(hipExtStreamCreateWithCUMask(&sa, (uint32_t)words, ma.data()));
-        HIP_CHECK(hipExtStreamCreateWithCUMask(&sm, (uint32_t)words, mb.data()));
-        pair = {sa, sm};
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&st.att, (uint32_t)words, ma.data()));
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&st.att2, (uint32_t)words, ma.data()));
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&st.mm, (uint32_t)words, mb.data()));
     }
-    m->stream_att = pair.first;
-    m->stream_mm = pair.second;
+    m->stream_att = st.att;
+    m->stream_att2 = st.att2;
+    m->stream_mm = st.mm;
     m->split_att_cus = att_cus;
 }
 
@@ -809,6 +809,10 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         const bool was_split = n_half == 2;
         if (was_split) ensure_split_streams(m, att_cus);
         bool chain = was_split;   // attention and the other kernels are on different streams
+        // The halves' attention launches on one stream or on two (both confined to the attention's CUs): on two, a
+        // launch starts filling CUs while the other half's previous launch drains, instead of ~11 us after its end.
+        const char* env_as = getenv("Q3ASR_ATT_STREAMS");
+        const int att_streams = was_split && env_as && atoi(env_as) == 2 ? 2 : 1;
         // The reference computes nothing for a clip once it has stopped (:571-574).  Here a stopped utterance is skipped by
         // the attention kernel at once (its done flag) and leaves the step's rows at the next poll: the step kernel
         // writes the list of utterances still running, and switching the row -> utterance map to that list shrinks
@@ -858,7 +862,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             x.n = n_half == 1 ? b : (h ? b - hv[0].n : (b + 1) / 2);
             x.cur = 0;
             x.s = was_split ? m->stream_mm : c.s;
-            x.sa = chain ? m->stream_att : c.s;
+            x.sa = chain ? (h && att_streams == 2 ? m->stream_att2 : m->stream_att) : c.s;
             x.hid = c.get<float>((size_t)x.n * H);
             x.xn = c.get<bf16_t>((size_t)x.n * H);
             x.qd = c.get<bf16_t>((size_t)x.n * nh * hd);
@@ -923,9 +927,11 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             for (int h = 0; h < 2; ++h) set_rows(hv[h], hv[h].n);
             HIP_CHECK(hipEventRecord(ev_fork, c.s));   // both streams start after everything queued so far
             HIP_CHECK(hipStreamWaitEvent(m->stream_att, ev_fork, 0));
+            if (att_streams == 2) HIP_CHECK(hipStreamWaitEvent(m->stream_att2, ev_fork, 0));
             HIP_CHECK(hipStreamWaitEvent(m->stream_mm, ev_fork, 0));
             if (prof_active(c.s)) {
                 prof_attach(c.s, m->stream_att);
+                if (att_streams == 2) prof_attach(c.s, m->stream_att2);
                 prof_attach(c.s, m->stream_mm);
             }
         } else {
@@ -977,6 +983,9 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             Half& x = hv[h];
             const DecLayerW& L = m->dec[l];
             if (chain) HIP_CHECK(hipStreamWaitEvent(x.sa, ev_pre[h][l], 0));
+            // two attention streams: a step's first launch of the second half starts behind the first half's, which sets
+            // the alternation the later layers keep by themselves (each half's next launch waits for its own projections)
+            if (chain && att_streams == 2 && h == 1 && l == 0 && hv[0].rows > 0) HIP_CHECK(hipStreamWaitEvent(x.sa, ev_attn[0][0], 0));
             if (prof_active(x.sa)) {
                 const bool timed = prof_next_timed("decode_attn_kernel", x.sa);
                 attn_launched[h * per_half + it] += 1;
@@ -1079,11 +1088,11 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             }
             if (ta > 0)
                 for (int h = 0; h < 2; ++h) {
-                    Half& x = hv[h];
-                    HIP_CHECK(hipStreamWaitEvent(x.sa, ev_xlast[h], 0));
-                    if (prof_active(x.sa)) launch_noop(x.sa);   // keeps a timed launch's start event behind the wait
-                    lm_part(h, 0, ta * 256, x.sa, att_cus);
-                    HIP_CHECK(hipEventRecord(ev_lm[h], x.sa));
+                    hipStream_t sl = hv[0].sa;   // both halves' shares on one stream: two persistent grids would contend for the same CUs
+                    HIP_CHECK(hipStreamWaitEvent(sl, ev_xlast[h], 0));
+                    if (prof_active(sl)) launch_noop(sl);   // keeps a timed launch's start event behind the wait
+                    lm_part(h, 0, ta * 256, sl, att_cus);
+                    HIP_CHECK(hipEventRecord(ev_lm[h], sl));
                 }
             for (int h = 0; h < 2; ++h) lm_part(h, ta * 256, cfg.vocab - ta * 256, hv[h].s, mm_cus);
             for (int h = 0; h < 2; ++h) {
@@ -1176,6 +1185,10 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             HIP_CHECK(hipStreamWaitEvent(c.s, ev_join, 0));
             HIP_CHECK(hipEventRecord(ev_join, m->stream_att));
             HIP_CHECK(hipStreamWaitEvent(c.s, ev_join, 0));
+            if (att_streams == 2) {
+                HIP_CHECK(hipEventRecord(ev_join, m->stream_att2));
+                HIP_CHECK(hipStreamWaitEvent(c.s, ev_join, 0));
+            }
         }
         cur_cus = 0;
         if (prof_active(c.s)) {

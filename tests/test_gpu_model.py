@@ -187,6 +187,12 @@ def test_split_decode_equals_one_stream(pinned_model, monkeypatch):
     monkeypatch.setenv("Q3ASR_LM_SPLIT", "0")
     two = m.transcribe_batch(audios, 16000, max_tokens=24)
     assert one.tokens == two.tokens
+    # opt-in: each half's attention on a stream of its own (both confined to the attention's compute units)
+    monkeypatch.setenv("Q3ASR_LM_SPLIT", "2")
+    monkeypatch.setenv("Q3ASR_ATT_STREAMS", "2")
+    two = m.transcribe_batch(audios, 16000, max_tokens=24)
+    assert one.tokens == two.tokens
+    monkeypatch.delenv("Q3ASR_ATT_STREAMS")
     monkeypatch.delenv("Q3ASR_LM_SPLIT")
     forced = np.tile(np.arange(100, 110, dtype=np.int32), (5, 1))
     a = m.transcribe_batch(audios, 16000, max_tokens=10, forced_tokens=forced, tap_steps=10)
