@@ -35,8 +35,9 @@ union Frag {
     uint2 h[2];
 };
 
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
+// G: query heads of one KV head that a workgroup computes against each staged K/V tile (1 or 2)
+template <int D, bool CAUSAL, int G>
+__global__ __launch_bounds__(256, G == 2 ? 2 : 1) void flash_kernel(FlashParams p) {
     constexpr int KS = D * 2 + 16;  // K row stride in LDS (bytes)
     constexpr int VS = 80;          // V^T row stride: 32 keys * 2 B + 16
     constexpr int KCH = D / 8;      // 16-byte chunks per row
@@ -49,14 +50,16 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const AttnTile tile = p.tiles[blockIdx.x];
     const AttnSeq seq = p.seqs[tile.seq];
-    const int h = blockIdx.y, kvh = h / p.group;
+    const int h0 = blockIdx.y * G, kvh = h0 / p.group;
     const int len = seq.len, q0 = tile.q0;
     const int qi = q0 + 16 * wave + li;
     const int64_t qrow = seq.q_row0 + min(qi, len - 1);
 
-    Frag qf[NKS];
+    Frag qf[G][NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks].u = *(const uint4*)(p.Q + qrow * p.q_ld + h * D + 32 * ks + 8 * lg);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[g][ks].u = *(const uint4*)(p.Q + qrow * p.q_ld + (h0 + g) * D + 32 * ks + 8 * lg);
 
     const int kv_end = CAUSAL ? min(len, q0 + 64) : len;
     const int ntiles = (kv_end + 31) >> 5;
@@ -80,10 +83,15 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
     FLASH_LOAD(0);
 
     const float sl2 = p.scale * 1.44269504088896340736f;
-    float m = -INFINITY, l = 0.f;
-    f32x4 o[NDT];
+    float m[G], l[G];
+    f32x4 o[G][NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[g][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
@@ -104,6 +112,8 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
         const int kv0 = t * 32;
         if (CAUSAL && kv0 > q0 + 16 * wave + 15) continue;  // wave-uniform: every key is in the future
 
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
         f32x4 s[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
             for (int ks = 0; ks < NKS; ++ks) {
                 Frag kf;
                 kf.u = *(const uint4*)(kl + (16 * nt + li) * KS + (lg + 4 * ks) * 16);
-                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qf[ks].v, s[nt], 0, 0, 0);
+                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qf[g][ks].v, s[nt], 0, 0, 0);
             }
         }
         float sv[8], tmax = -INFINITY;
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
             }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = exp2f(m - m_new);
+        const float m_new = fmaxf(m[g], tmax);
+        const float alpha = exp2f(m[g] - m_new);
         float ps = 0.f, pe[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -138,26 +148,31 @@ __global__ __launch_bounds__(256) void flash_kernel(FlashParams p) {
         Frag pf;
         pf.u = make_uint4(pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3]), pack_bf16x2(pe[4], pe[5]),
                           pack_bf16x2(pe[6], pe[7]));
-        l = l * alpha + ps;
-        m = m_new;
+        l[g] = l[g] * alpha + ps;
+        m[g] = m_new;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            o[dt] *= alpha;
+            o[g][dt] *= alpha;
             Frag vf;
             vf.h[0] = *(const uint2*)(vl + (16 * dt + li) * VS + 8 * lg);
             vf.h[1] = *(const uint2*)(vl + (16 * dt + li) * VS + 32 + 8 * lg);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
+            o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[g][dt], 0, 0, 0);
+        }
         }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (qi < len) {
-        const float inv = 1.0f / l;
-        bf16_t* orow = p.O + (seq.q_row0 + qi) * p.o_ld + h * D + 4 * lg;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-            *(uint2*)(orow + 16 * dt) =
-                make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+    for (int g = 0; g < G; ++g) {
+        float lt = l[g];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        if (qi < len) {
+            const float inv = 1.0f / lt;
+            bf16_t* orow = p.O + (seq.q_row0 + qi) * p.o_ld + (h0 + g) * D + 4 * lg;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+                *(uint2*)(orow + 16 * dt) = make_uint2(pack_bf16x2(o[g][dt][0] * inv, o[g][dt][1] * inv),
+                                                       pack_bf16x2(o[g][dt][2] * inv, o[g][dt][3] * inv));
+        }
     }
 }
 
@@ -422,15 +437,20 @@ void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s, double
     if (p.n_tiles <= 0) return;
     Q3_REQUIRE(head_dim == 64 || head_dim == 128, "flash attention: head_dim must be 64 or 128");
     Q3_REQUIRE(p.q_ld % 8 == 0 && p.kv_ld % 8 == 0 && p.kv_hs % 8 == 0 && p.o_ld % 4 == 0, "flash attention: misaligned strides");
-    dim3 grid(p.n_tiles, p.heads), block(256);
+    // grouped-query decoder attention: the query heads of a KV head come in pairs, and a workgroup that computes a
+    // pair stages every K/V tile once for both (Q3ASR_FLASH_PAIR=0: one head per workgroup)
+    const char* env_pair = getenv("Q3ASR_FLASH_PAIR");
+    const bool pair = head_dim == 128 && p.causal && p.group % 2 == 0 && p.heads % 2 == 0 && !(env_pair && atoi(env_pair) == 0);
+    dim3 grid(p.n_tiles, pair ? p.heads / 2 : p.heads), block(256);
     ProfScope ps(head_dim == 64 ? (p.causal ? "flash_kernel<64,true>" : "flash_kernel<64,false>")
                                 : (p.causal ? "flash_kernel<128,true>" : "flash_kernel<128,false>"), work, s);
     if (head_dim == 64) {
-        if (p.causal) hipLaunchKernelGGL((flash_kernel<64, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_kernel<64, false>), grid, block, 0, s, p);
+        if (p.causal) hipLaunchKernelGGL((flash_kernel<64, true, 1>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_kernel<64, false, 1>), grid, block, 0, s, p);
     } else {
-        if (p.causal) hipLaunchKernelGGL((flash_kernel<128, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_kernel<128, false>), grid, block, 0, s, p);
+        if (pair) hipLaunchKernelGGL((flash_kernel<128, true, 2>), grid, block, 0, s, p);
+        else if (p.causal) hipLaunchKernelGGL((flash_kernel<128, true, 1>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_kernel<128, false, 1>), grid, block, 0, s, p);
     }
     HIP_CHECK(hipGetLastError());
 }
