@@ -112,52 +112,59 @@ __global__ __launch_bounds__(256, G == 2 ? 2 : 1) void flash_kernel(FlashParams 
         const int kv0 = t * 32;
         if (CAUSAL && kv0 > q0 + 16 * wave + 15) continue;  // wave-uniform: every key is in the future
 
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-        f32x4 s[2];
+        // every K and V fragment is read from LDS once and used for all G heads
+        f32x4 s[G][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < G; ++g) s[g][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 Frag kf;
                 kf.u = *(const uint4*)(kl + (16 * nt + li) * KS + (lg + 4 * ks) * 16);
-                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qf[g][ks].v, s[nt], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) s[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qf[g][ks].v, s[g][nt], 0, 0, 0);
             }
         }
-        float sv[8], tmax = -INFINITY;
+        Frag pf[G];
+        float alpha[G];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int g = 0; g < G; ++g) {
+            float sv[8], tmax = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kv0 + 16 * nt + 4 * lg + r;
-                const bool ok = key < len && (!CAUSAL || key <= qi);
-                sv[nt * 4 + r] = ok ? s[nt][r] * sl2 : -INFINITY;
-                tmax = fmaxf(tmax, sv[nt * 4 + r]);
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + 16 * nt + 4 * lg + r;
+                    const bool ok = key < len && (!CAUSAL || key <= qi);
+                    sv[nt * 4 + r] = ok ? s[g][nt][r] * sl2 : -INFINITY;
+                    tmax = fmaxf(tmax, sv[nt * 4 + r]);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m[g], tmax);
+            alpha[g] = exp2f(m[g] - m_new);
+            float ps = 0.f, pe[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pe[j] = exp2f(sv[j] - m_new);
+                ps += pe[j];
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m[g], tmax);
-        const float alpha = exp2f(m[g] - m_new);
-        float ps = 0.f, pe[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            pe[j] = exp2f(sv[j] - m_new);
-            ps += pe[j];
+            pf[g].u = make_uint4(pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3]), pack_bf16x2(pe[4], pe[5]),
+                                 pack_bf16x2(pe[6], pe[7]));
+            l[g] = l[g] * alpha[g] + ps;
+            m[g] = m_new;
         }
-        Frag pf;
-        pf.u = make_uint4(pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3]), pack_bf16x2(pe[4], pe[5]),
-                          pack_bf16x2(pe[6], pe[7]));
-        l[g] = l[g] * alpha + ps;
-        m[g] = m_new;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            o[g][dt] *= alpha;
             Frag vf;
             vf.h[0] = *(const uint2*)(vl + (16 * dt + li) * VS + 8 * lg);
             vf.h[1] = *(const uint2*)(vl + (16 * dt + li) * VS + 32 + 8 * lg);
-            o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[g][dt], 0, 0, 0);
-        }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                o[g][dt] *= alpha[g];
+                o[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[g].v, o[g][dt], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
