@@ -37,13 +37,13 @@ union Frag {
 
 // G: query heads of one KV head that a workgroup computes against each staged K/V tile (1 or 2)
 template <int D, bool CAUSAL, int G>
-__global__ __launch_bounds__(256, G == 2 ? 2 : 1) void flash_kernel(FlashParams p) {
+__global__ __launch_bounds__(256, G == 2 ? 3 : 1) void flash_kernel(FlashParams p) {
     constexpr int KS = D * 2 + 16;  // K row stride in LDS (bytes)
-    constexpr int VS = 80;          // V^T row stride: 32 keys * 2 B + 16
+    constexpr int VS = D * 2 + 32;  // V row stride: the transposing reads of a 32-lane half (8 rows x 4 column quads) then hit 64 distinct banks
     constexpr int KCH = D / 8;      // 16-byte chunks per row
     constexpr int NLD = 32 * KCH / 256;
     constexpr int NKS = D / 32, NDT = D / 16;
-    __shared__ __attribute__((aligned(16))) char lds[32 * KS + D * VS];
+    __shared__ __attribute__((aligned(16))) char lds[32 * KS + 32 * VS];
     char* kl = lds;
     char* vl = lds + 32 * KS;
 
@@ -67,19 +67,22 @@ __global__ __launch_bounds__(256, G == 2 ? 2 : 1) void flash_kernel(FlashParams 
     const bf16_t* Vb = p.V + seq.kv_off + (int64_t)kvh * p.kv_hs;
 
     uint4 kreg0, kreg1, vreg0, vreg1;
-    const int v_kp = tid & 15, v_ch = tid >> 4;  // V item: key pair, chunk
     const int k_key0 = tid / KCH, k_ch0 = tid % KCH, k_key1 = (tid + 256) / KCH, k_ch1 = (tid + 256) % KCH;
 #define FLASH_LOAD(t)                                                                                   \
     {                                                                                                   \
         const int kv0_ = (t) * 32;                                                                      \
-        kreg0 = *(const uint4*)(Kb + (int64_t)min(kv0_ + k_key0, len - 1) * p.kv_ld + k_ch0 * 8);       \
-        if constexpr (NLD > 1)                                                                          \
-            kreg1 = *(const uint4*)(Kb + (int64_t)min(kv0_ + k_key1, len - 1) * p.kv_ld + k_ch1 * 8);   \
-        if (v_ch < KCH) {                                                                               \
-            vreg0 = *(const uint4*)(Vb + (int64_t)min(kv0_ + 2 * v_kp, len - 1) * p.kv_ld + v_ch * 8);  \
-            vreg1 = *(const uint4*)(Vb + (int64_t)min(kv0_ + 2 * v_kp + 1, len - 1) * p.kv_ld + v_ch * 8); \
+        const int64_t r0_ = (int64_t)min(kv0_ + k_key0, len - 1) * p.kv_ld + k_ch0 * 8;                 \
+        kreg0 = *(const uint4*)(Kb + r0_);                                                              \
+        vreg0 = *(const uint4*)(Vb + r0_);                                                              \
+        if constexpr (NLD > 1) {                                                                        \
+            const int64_t r1_ = (int64_t)min(kv0_ + k_key1, len - 1) * p.kv_ld + k_ch1 * 8;             \
+            kreg1 = *(const uint4*)(Kb + r1_);                                                          \
+            vreg1 = *(const uint4*)(Vb + r1_);                                                          \
         }                                                                                               \
     }
+    // V stays row-major in LDS; the A fragments of O^T = V^T P^T are transposing reads (per 16 lanes a block of 4 keys x 16
+    // dims, lane 4q + p supplying the address of key q, dims 4p..4p+3, lane i receiving dim i of the 4 keys)
+    const char* vr = vl + (4 * lg + (li >> 2)) * VS + (li & 3) * 8;
     FLASH_LOAD(0);
 
     const float sl2 = p.scale * 1.44269504088896340736f;
@@ -97,16 +100,8 @@ __global__ __launch_bounds__(256, G == 2 ? 2 : 1) void flash_kernel(FlashParams 
         __syncthreads();
         *(uint4*)(kl + k_key0 * KS + k_ch0 * 16) = kreg0;
         if constexpr (NLD > 1) *(uint4*)(kl + k_key1 * KS + k_ch1 * 16) = kreg1;
-        if (v_ch < KCH) {
-            const uint32_t aw[4] = {vreg0.x, vreg0.y, vreg0.z, vreg0.w};
-            const uint32_t bw[4] = {vreg1.x, vreg1.y, vreg1.z, vreg1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t ae = (e & 1) ? (aw[e >> 1] >> 16) : (aw[e >> 1] & 0xffffu);
-                const uint32_t be = (e & 1) ? (bw[e >> 1] & 0xffff0000u) : (bw[e >> 1] << 16);
-                *(uint32_t*)(vl + (v_ch * 8 + e) * VS + v_kp * 4) = ae | be;
-            }
-        }
+        *(uint4*)(vl + k_key0 * VS + k_ch0 * 16) = vreg0;
+        if constexpr (NLD > 1) *(uint4*)(vl + k_key1 * VS + k_ch1 * 16) = vreg1;
         __syncthreads();
         if (t + 1 < ntiles) FLASH_LOAD(t + 1);
         const int kv0 = t * 32;
@@ -157,9 +152,12 @@ __global__ __launch_bounds__(256, G == 2 ? 2 : 1) void flash_kernel(FlashParams 
         }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
+            union { s16x4 v; uint2 u; } lo, hi;   // keys 4 lg .. 4 lg + 3 and 16 + 4 lg .. of dim 16 dt + li
+            lo.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vr + 32 * dt));
+            hi.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vr + 16 * VS + 32 * dt));
             Frag vf;
-            vf.h[0] = *(const uint2*)(vl + (16 * dt + li) * VS + 8 * lg);
-            vf.h[1] = *(const uint2*)(vl + (16 * dt + li) * VS + 32 + 8 * lg);
+            vf.h[0] = lo.u;
+            vf.h[1] = hi.u;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 o[g][dt] *= alpha[g];
