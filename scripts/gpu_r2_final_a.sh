@@ -1,4 +1,4 @@
-# Round-2 evidence, part A: the whole GPU test suite, the default bench line (with its CPU baseline), rocprofv3 kernel
+# Measurement set, part A: the whole GPU test suite, the default bench line (with its CPU baseline), rocprofv3 kernel
 # stats of the same command and the HBM traffic counters of the decode attention (one counter per pass).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}

@@ -1,4 +1,4 @@
-# Round-2 evidence, part B: rocprofv3 kernel stats of the default bench command and the HBM traffic counters of the decode
+# Measurement set, part B: rocprofv3 kernel stats of the default bench command and the HBM traffic counters of the decode
 # attention (one counter per pass).  The summaries are written even if the profiled program ends badly; nothing further
 # runs after a bad exit.
 set -o pipefail

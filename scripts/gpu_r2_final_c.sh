@@ -1,4 +1,4 @@
-# Round-2 evidence, part C: the full-size tests (incl. the headline configuration), the default bench line with its CPU
+# Measurement set, part C: the full-size tests (incl. the headline configuration), the default bench line with its CPU
 # baseline, then the labelled variants and the other configurations.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}

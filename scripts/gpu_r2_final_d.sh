@@ -1,4 +1,4 @@
-# Round-2 evidence, part D: the whole GPU test suite on the final tree, then one counter pass for the matrix-pipe
+# Measurement set, part D: the whole GPU test suite on the final tree, then one counter pass for the matrix-pipe
 # utilisation of every kernel (512 clips, 16 tokens).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -13,7 +13,7 @@ timeout -s KILL 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
 echo "pmc rc=$rc"
 [ $rc -eq 0 ] || { tail -3 $O/mfma.err; exit 1; }
 F=$(find /tmp/prof/mfma -name "*counter_collection.csv" | head -1)
-python3 $R/scripts/pmc_mfma_util.py $F "1.7b, 512 clips x 30 s, max_tokens 16 (encoder + prefill + 15 decode steps), round-2 kernels" > $O/pmc_mfma_util_b512.json
+python3 $R/scripts/pmc_mfma_util.py $F "1.7b, 512 clips x 30 s, max_tokens 16 (encoder + prefill + 15 decode steps)" > $O/pmc_mfma_util_b512.json
 python3 - <<PY
 import json
 d=json.load(open("$O/pmc_mfma_util_b512.json"))

@@ -1,4 +1,4 @@
-# Round-2 evidence on the final build: the whole GPU test suite, the default bench line with its CPU baseline, rocprofv3
+# Measurement set on the final build: the whole GPU test suite, the default bench line with its CPU baseline, rocprofv3
 # kernel stats of the same command, and the two labelled variants of the headline.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}

@@ -1,4 +1,4 @@
-# Round-2 measurement set: full GPU test suite, the default bench line (with CPU baseline), the labelled variants,
+# Measurement set: full GPU test suite, the default bench line (with CPU baseline), the labelled variants,
 # other configurations, then rocprofv3 kernel stats + PMC traffic of the same default command.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}

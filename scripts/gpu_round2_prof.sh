@@ -1,4 +1,4 @@
-# rocprofv3 evidence for round 2: kernel-trace stats of the default bench command, then one counter per pass
+# rocprofv3 evidence: kernel-trace stats of the default bench command, then one counter per pass
 # (FETCH_SIZE, WRITE_SIZE) for the decode attention and the log-mel kernel.  Outputs under gpurun_out/prof3/.
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
