@@ -7,6 +7,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "qwen3-asr-swift_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the library's decode loop reports its host-side progress on stderr: pytest shows it only for a test that fails or
 # times out, which is where one wants to know at which step a call stood
@@ -15,6 +16,16 @@ os.environ.setdefault("Q3ASR_TRACE", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Every bound beside the value measured under it, and how many token comparisons were asserted."""
+    import parity
+    lines = parity.write_report(ROOT)
+    if lines:
+        terminalreporter.section("parity: measured against bounds")
+        for ln in lines:
+            terminalreporter.write_line(ln)
 
 
 def bf16_bits(x):
