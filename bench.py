@@ -129,22 +129,44 @@ def free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(n, argv, child=None):
+def spawn_ranks(n, argv, child=None, poll_s=0.2, grace_s=5.0):
     """`python bench.py --gpus N` without a launcher: start N copies of this script, one rank per GPU, before this
-    process has touched the GPU; pass rank 0's result line through; fail if any rank fails."""
+    process has touched the GPU, and watch all of them.  Rank 0's result line is passed through once every rank has
+    ended well.  The first rank that ends badly ends the job: its siblings (which would otherwise sit in a collective
+    until the backend's timeout) are terminated, killed if they ignore that for `grace_s` seconds, and the launcher
+    exits non-zero naming the rank and its exit code."""
     import subprocess
+    import tempfile
     child = child or [sys.executable, os.path.abspath(__file__)]
     port = int(os.environ.get("MASTER_PORT") or free_port())
     procs = []
-    for r, env in enumerate(rank_envs(n, port)):
-        procs.append(subprocess.Popen(child + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r, env in enumerate(rank_envs(n, port)):
+            procs.append(subprocess.Popen(child + list(argv), env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+        bad = None
+        while bad is None and any(p.poll() is None for p in procs):
+            time.sleep(poll_s)
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    bad = (r, p.returncode)
+                    break
+        if bad is None:
+            bad = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+        if bad is not None:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.monotonic() + grace_s
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.0, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            raise SystemExit(f"bench.py: rank {bad[0]} ended with exit code {bad[1]}; the other ranks were stopped, no result")
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
     return 0
 
 
@@ -179,9 +201,13 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with one GPU, together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--collective-timeout", type=float, default=240.0, help="seconds after which a collective that a rank never "
+                    "joins is given up (the process group's timeout): ranks differ by their set-up time at most")
     ap.add_argument("--rehearse-collectives", action="store_true", help="one rank only: open a process group of one rank on "
                     "--backend anyway and run the job's exchange (all_gather of token lists, all_reduce of counters, barriers) "
                     "through it -- the RCCL calls of a multi-GPU run, on a box with one GPU")
+    ap.add_argument("--leak-model", action="store_true", help="diagnostic: end the process without q3asr_destroy, like a host whose "
+                    "finaliser never runs (the library's own exit handler then has to release the model)")
     ap.add_argument("--workload", default="transcribe", choices=["transcribe", "mel", "ragged"],
                     help="transcribe: the headline run, --batch clips of --clip-seconds per GPU.  mel: the log-mel frontend alone on the "
                          "same clips (device buffers in and out).  ragged: --utterances recordings per GPU with durations U[5, 300] s "
@@ -205,10 +231,12 @@ def main():
     def emit(line):
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 
+    import datetime
     import torch
     import torch.distributed as dist
     from q3asr import Qwen3ASRModel, make_config, synth
 
+    t_setup = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,13 +251,22 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        timeout = datetime.timedelta(seconds=args.collective_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timeout)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=timeout)
+        world = dist.get_world_size()      # what the group really holds, not what the environment promised
+        rank = dist.get_rank()
 
+    # Set-up is host work that every rank of a node does at once on its share of the cores: the weights are drawn on
+    # a few threads per rank, and a rank's clips repeat 64 distinct seeded ones (kernel times do not depend on the
+    # sample values; the tests' full-size batches are built the same way).
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    workers = max(2, min(16, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     cfg = make_config(args.preset, max_batch=args.batch, weight_format=1 if args.weights == "q4" else 0)
-    ck = synth.make_checkpoint(cfg, seed=0)
+    ck = synth.make_checkpoint(cfg, seed=0, workers=workers)
     model = Qwen3ASRModel.from_checkpoint(cfg, ck, device=local_rank)
     if args.workload == "ragged":
         # Every rank derives the same recording list, keeps its cost-balanced share and numbers the pieces globally.
@@ -253,11 +290,12 @@ def main():
                 f"{n_units_total} pieces over {world} GPU(s), cost-sharded, groups of {args.batch} length-sorted pieces")
     else:
         n = int(args.clip_seconds * 16000)
-        clips = [synth.synth_audio(n, 1234 + rank * args.batch + i, args.audio) for i in range(args.batch)]
+        base = [synth.synth_audio(n, 1234 + rank * 64 + i, args.audio) for i in range(min(64, args.batch))]
+        clips = [base[i % len(base)] for i in range(args.batch)]
         piece_ids = [rank * args.batch + i for i in range(args.batch)]
         offsets = np.arange(args.batch + 1, dtype=np.int64) * n
         n_units_total = world * args.batch
-        what = f"{args.batch} x {args.clip_seconds:g} s synthetic 16 kHz clips per GPU per step"
+        what = f"{args.batch} x {args.clip_seconds:g} s synthetic 16 kHz clips per GPU per step ({len(base)} distinct seeded clips, repeated)"
     forced = None
     if args.length_dist != "none":
         lens_tok = scripted_lengths(args.length_dist, len(piece_ids), args.max_tokens, 99 + rank)
@@ -305,6 +343,13 @@ def main():
             last_note[0] = now
             print(f"[bench] {what}", file=sys.stderr, flush=True)
 
+    setup_s = time.perf_counter() - t_setup
+    # who is really there: every rank's device and set-up time, gathered through the group
+    me = {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank), "setup_s": round(setup_s, 1)}
+    ranks_seen = [me]
+    if group:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
     note("weights and audio resident, starting the warmup steps")
     for i in range(args.warmup):
         step()
@@ -348,6 +393,10 @@ def main():
                   else f"RTFx (audio s per wall s) node-wide, {args.preset} {args.weights}, 30 s clips")
         label = (f"Qwen3-ASR-{args.preset} {args.weights} full transcribe (mel+encoder+prefill+greedy decode, reference stop "
                  f"rules, max_tokens {args.max_tokens}), {what}, audio resident in HBM, seeded random weights of the true shapes; {lengths}")
+    if args.share_gpu or args.rehearse_collectives:
+        # a run that shares one GPU between ranks, or pushes one rank through the collectives, checks plumbing: its
+        # number must not read like a throughput result
+        metric = "REHEARSAL of the multi-rank path (not a throughput result): " + metric
     if rank == 0 and not prof:
         ms = {k: sum(o.ms[k] for o in outs) / args.steps for k in outs[0].ms}
         emit({"metric": metric, "value": round(audio_s / dt, 2),
@@ -355,7 +404,8 @@ def main():
                           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32" if args.workload == "mel" else "bf16", "data": "synthetic",
                           "config": {"workload": "run without kernel timing: " + label, "clips_per_gpu": n_local,
-                                     "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}},
+                                     "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()},
+                                     "ranks_seen": len(ranks_seen), "ranks": ranks_seen},
                           "roofline": None, "cpu_baseline": None})
     elif rank == 0:
         # dominant kernel by device time (sampled HIP-event timings scaled to all launches)
@@ -382,6 +432,7 @@ def main():
                        "clips_per_gpu": n_local, "tokens_per_clip": round(tokens / (n_units_total * args.steps), 1),
                        "decode_row_steps_per_clip": round(row_steps / (n_units_total * args.steps), 1),
                        "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in ms.items()}, "sharding": f"utterance-dp{world}",
+                       "ranks_seen": len(ranks_seen), "ranks": ranks_seen,
                        # > 0: the group decodes as two halves, their attention kernels on this many CUs beside the
                        # other kernels on the rest (kernel times then overlap: they sum to more than the stage time)
                        "decode_attention_cus": 0 if args.workload == "mel" else model.decode_attention_cus(min(n_local, args.batch))},
@@ -391,13 +442,16 @@ def main():
             "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
                          "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:16]],
         }
-        model.close()
+        if not args.leak_model:
+            model.close()
         del dev_audio
         if world == 1 and not args.no_cpu_baseline and args.workload == "transcribe" and args.weights == "bf16":
             line["cpu_baseline"] = cpu_baseline(cfg, ck, clips[0], args.cpu_decode_steps)
         else:
             line["cpu_baseline"] = None
         emit(line)
+    if args.leak_model:
+        model._h = None    # the handle is dropped without q3asr_destroy
     model.close()          # streams and events are released before the process (and any profiler around it) winds down
     if group:
         dist.barrier()

@@ -74,8 +74,11 @@ int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_
  * (256 clips of 30 s) per call, at most 600 s per utterance; anything larger is rejected with an error.  audio_dev and
  * mel_out_dev ([n_utt][128][t_stride] fp32) are device pointers, offsets ([n_utt + 1]) and n_frames ([n_utt]) host
  * pointers.  stream: a hipStream_t to enqueue on (the call then returns without waiting), or NULL for the model's own
- * stream (the call then waits, like q3asr_mel).  All calls on one GPU share the array: calls that overlap on one GPU
- * race (calls through one model are serialised; do not run it from two models on one GPU at once). */
+ * stream (the call then waits, like q3asr_mel).  All calls on one GPU share the array, through whichever model or stream
+ * they come; the library runs them one after the other on the device (each call's stream first waits for an event
+ * recorded behind the previous call's last kernel), so asynchronous calls on different streams do not race.  The one
+ * exception is a stream under graph capture, which can neither wait for that event nor record it: replays of a captured
+ * call must not overlap each other or any other call of this entry point on the same GPU. */
 int q3asr_mel_noalloc(q3asr_model* m, const float* audio_dev, const int64_t* offsets, int n_utt, float* mel_out_dev, int t_stride,
                       int32_t* n_frames, void* stream);
 

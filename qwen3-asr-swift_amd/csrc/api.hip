@@ -1,12 +1,23 @@
 // extern "C" surface of libq3asr (declared in include/q3asr.h).
 #include "model.h"
 #include "prof.h"
+#include <cstdlib>
 #include <cstring>
+#include <set>
 
 static thread_local std::string g_last_error;
 void q3_set_error(const std::string& msg) { g_last_error = msg; }
 
-#define Q3_API_BEGIN try {
+static thread_local Q3Knobs g_knobs;
+Q3Knobs& q3_knobs() { return g_knobs; }
+void q3_knobs_refresh() {
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    g_knobs.flash_pair = num("Q3ASR_FLASH_PAIR", -1);
+    g_knobs.attn_waves = num("Q3ASR_ATTN_WAVES", 0);
+    g_knobs.force_tile = num("Q3ASR_FORCE_TILE", -1);
+}
+
+#define Q3_API_BEGIN try { q3_knobs_refresh();
 #define Q3_API_END                         \
     g_last_error.clear();                  \
     return 0;                              \
@@ -19,6 +30,50 @@ void q3_set_error(const std::string& msg) { g_last_error = msg; }
         g_last_error = "q3asr: unknown error"; \
         return 2;                          \
     }
+
+// Models that exist.  A host may end without calling q3asr_destroy (a Swift deinit is not guaranteed at process exit,
+// nor is a Python __del__), which would leave streams, CU-masked queues, events and device memory for the HIP
+// runtime's own exit handlers to find alive; under a profiler that ended in a segmentation fault inside the runtime's
+// static destruction.  So the library destroys what is left itself, from an exit handler registered right after the
+// first successful HIP call of the first q3asr_create: handlers run in reverse order of registration, i.e. this one
+// before anything the runtime registered while it initialised.  The registry and its mutex are never destructed
+// (no static destructor of this library calls HIP), and q3asr_destroy ignores a handle that is not in the registry
+// (destroyed twice, or destroyed by the exit handler before a late finaliser of the host got to it).
+namespace {
+struct LiveModels {
+    std::mutex mu;
+    std::set<q3asr_model*> set;
+};
+LiveModels& live_models() {
+    static LiveModels* p = new LiveModels();
+    return *p;
+}
+void destroy_model(q3asr_model* m) {
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    try { (void)prof_stop(m->stream); } catch (...) {}   // a profile left running must not outlive its streams
+    mel_tables_destroy(m->mel);
+    m->arena.release();
+    for (void* p : m->owned) (void)hipFree(p);
+    for (hipEvent_t e : m->chain_events) (void)hipEventDestroy(e);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+void destroy_live_models_at_exit() {
+    std::set<q3asr_model*> left;
+    {
+        std::lock_guard<std::mutex> lk(live_models().mu);
+        left.swap(live_models().set);
+    }
+    bool busy = false;
+    for (q3asr_model* m : left) {
+        if (!m->call_mutex.try_lock()) { busy = true; continue; }   // a call still runs on another thread: leave that model alone
+        m->call_mutex.unlock();
+        destroy_model(m);
+    }
+    if (!busy) model_release_process_streams();
+}
+}  // namespace
 
 extern "C" {
 
@@ -46,6 +101,9 @@ int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
     Q3_REQUIRE(cfg->n_window_infer > 0 && cfg->n_window_infer % (2 * cfg->n_window) == 0, "create: n_window_infer must be a multiple of the chunk length");
     Q3_REQUIRE(cfg->conv_channels > 0 && cfg->enc_layers > 0 && cfg->layers > 0 && cfg->vocab > 0 && cfg->max_batch >= 0, "create: non-positive size");
     HIP_CHECK(hipSetDevice(device));
+    static std::once_flag exit_hook;
+    // (Q3ASR_NO_EXIT_HOOK=1 leaves the handler out: a diagnostic switch for showing what it is there to prevent)
+    std::call_once(exit_hook, [] { if (!getenv("Q3ASR_NO_EXIT_HOOK")) atexit(destroy_live_models_at_exit); });
     q3asr_model* m = new q3asr_model();
     m->cfg = *cfg;
     m->device = device;
@@ -58,8 +116,12 @@ int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
         mel_tables_create(m->mel);
         mel_noalloc_init();
     } catch (...) {
-        q3asr_destroy(m);
+        destroy_model(m);
         throw;
+    }
+    {
+        std::lock_guard<std::mutex> lk(live_models().mu);
+        live_models().set.insert(m);
     }
     *out = m;
     Q3_API_END
@@ -67,18 +129,12 @@ int q3asr_create(const q3asr_config* cfg, int device, q3asr_model** out) {
 
 void q3asr_destroy(q3asr_model* m) {
     if (!m) return;
-    (void)hipSetDevice(m->device);
-    (void)hipDeviceSynchronize();
-    try { (void)prof_stop(m->stream); } catch (...) {}   // a profile left running must not outlive its streams
-    mel_tables_destroy(m->mel);
-    m->arena.release();
-    for (void* p : m->owned) (void)hipFree(p);
-    for (hipEvent_t e : m->chain_events) (void)hipEventDestroy(e);
-    for (auto& kv : m->split_streams)
-        for (hipStream_t s : {kv.second.att, kv.second.att2, kv.second.mm})
-            if (s) (void)hipStreamDestroy(s);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
-    delete m;
+    {
+        std::lock_guard<std::mutex> lk(live_models().mu);
+        if (live_models().set.erase(m) == 0) return;   // not (or no longer) a live model
+    }
+    { std::lock_guard<std::mutex> wait_for_a_running_call(m->call_mutex); }
+    destroy_model(m);
 }
 
 int q3asr_load_tensor(q3asr_model* m, const char* name, int dtype, const int64_t* shape, int ndim, const void* data) {

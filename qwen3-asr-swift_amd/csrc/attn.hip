@@ -444,8 +444,7 @@ void launch_flash_attn(const FlashParams& p, int head_dim, hipStream_t s, double
     Q3_REQUIRE(p.q_ld % 8 == 0 && p.kv_ld % 8 == 0 && p.kv_hs % 8 == 0 && p.o_ld % 4 == 0, "flash attention: misaligned strides");
     // grouped-query decoder attention: the query heads of a KV head come in pairs, and a workgroup that computes a
     // pair stages every K/V tile once for both (Q3ASR_FLASH_PAIR=0: one head per workgroup)
-    const char* env_pair = getenv("Q3ASR_FLASH_PAIR");
-    const bool pair = head_dim == 128 && p.causal && p.group % 2 == 0 && p.heads % 2 == 0 && !(env_pair && atoi(env_pair) == 0);
+    const bool pair = head_dim == 128 && p.causal && p.group % 2 == 0 && p.heads % 2 == 0 && q3_knobs().flash_pair != 0;
     dim3 grid(p.n_tiles, pair ? p.heads / 2 : p.heads), block(256);
     ProfScope ps(head_dim == 64 ? (p.causal ? "flash_kernel<64,true>" : "flash_kernel<64,false>")
                                 : (p.causal ? "flash_kernel<128,true>" : "flash_kernel<128,false>"), work, s);
@@ -464,8 +463,8 @@ void launch_decode_attn(const DecodeAttnParams& p, int head_dim, hipStream_t s, 
     if (p.B <= 0) return;
     Q3_REQUIRE(head_dim == 128, "decode attention: head_dim must be 128");
     const int items = p.B * p.kv_heads;
-    const char* env_waves = getenv("Q3ASR_ATTN_WAVES");   // 4 or 8: pins the variant (tests, tuning)
-    const bool wide = env_waves ? atoi(env_waves) == 8 : items < 256;   // fewer items than CUs: eight waves per item
+    const int pin_waves = q3_knobs().attn_waves;           // 4 or 8: pins the variant (tests, tuning)
+    const bool wide = pin_waves ? pin_waves == 8 : items < 256;   // fewer items than CUs: eight waves per item
     dim3 grid(p.max_blocks > 0 ? std::min(items, p.max_blocks) : items), block(wide ? 512 : 256);
     ProfScope ps("decode_attn_kernel", work, s);
     const bool fused = p.rope.qkv || p.rope.slab;

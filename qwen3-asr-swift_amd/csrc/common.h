@@ -45,18 +45,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_buffer(const void* bas
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
 }
-// Exact (erf) GELU, 0.5 x (1 + erf(x / sqrt 2)) (AudioEncoder.swift:379-384, 127-129: MLX gelu).  erf by the rational
-// approximation of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in erf, measured 4.7e-7 absolute in the GELU over
-// [-8, 8]): two transcendental instructions and a dozen multiply-adds instead of the library erff's ~30 instructions.
-// Every caller rounds the result to bf16 (relative step 4e-3), so the difference from a correctly rounded erf is
-// invisible except as the odd flipped rounding, like any other fp32 evaluation order.
+// Exact (erf) GELU, 0.5 x (1 + erf(x / sqrt 2)) (AudioEncoder.swift:379-384, 127-129: MLX gelu).  erfc(|z|) = p e by the
+// rational approximation of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in erf): two transcendental instructions
+// and a dozen multiply-adds instead of the library erff's ~30 instructions.  1 + erf(z) is p e for z < 0 and 2 - p e
+// otherwise, so the negative tail is a product, not a cancellation: the GELU keeps the approximation's own relative
+// accuracy there (3e-5 at x = -3, 7e-4 at x = -4.2, below one bf16 step of 3.9e-3 down to x = -6, where the value is
+// 1e-8) and 5e-7 absolute everywhere.  Every caller rounds the result to bf16.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = x * 0.70710678118654752440f, a = fabsf(z);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
     const float p = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
-    const float er = copysignf(fmaf(-p, e, 1.0f), z);
-    return 0.5f * x * (1.0f + er);
+    const float pe = p * e;
+    return 0.5f * x * (z < 0.0f ? pe : 2.0f - pe);
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -71,6 +72,17 @@ __device__ __forceinline__ float wave_max(float v) {
 #endif
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Environment switches the kernel launchers look at (tests and tuning runs pin a kernel variant with them).  They are
+// read once at the start of every API call into a snapshot that belongs to the calling thread: a decode step launches
+// tens of thousands of kernels, and getenv is not safe against a host thread that calls setenv meanwhile.
+struct Q3Knobs {
+    int flash_pair = -1;   // Q3ASR_FLASH_PAIR: 0 = one query head per workgroup in the prefill attention
+    int attn_waves = 0;    // Q3ASR_ATTN_WAVES: 4 or 8 pins the decode attention's wave count
+    int force_tile = -1;   // Q3ASR_FORCE_TILE: 0..3 pins the GEMM tile where the choice is automatic
+};
+Q3Knobs& q3_knobs();
+void q3_knobs_refresh();
 
 // One-time set-up per HIP device (function attributes, device properties): several models on several devices and
 // several host threads may reach a launcher at once.  A set-up that throws is retried by the next caller.

@@ -407,10 +407,8 @@ void launch_out(const GemmParams& p, GemmOut out, int tile, hipStream_t s) {
 
 int gemm_pick_tile(int M, int N) {
     // Q3ASR_FORCE_TILE pins the automatic choice (parity tests run small models through every tile)
-    if (const char* f = getenv("Q3ASR_FORCE_TILE")) {
-        const int t = atoi(f);
-        if (t >= 0 && t <= 3) return t;
-    }
+    const int pin = q3_knobs().force_tile;
+    if (pin >= 0 && pin <= 3) return pin;
     const int64_t t256 = (int64_t)cdiv(M, 256) * cdiv(N, 256);
     if (t256 >= 224) return 3;  // about one workgroup per CU or more
     const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);

@@ -492,8 +492,13 @@ void launch_mel_normalize(float* out, int B, int t_stride, const int* d_frames_o
 // that forbid it).  Same kernels as the allocating path; what that path takes from the model's workspace (utterance
 // offsets and lengths on the device, the tile list, the per-utterance running maximum, the frame counts) lives in a
 // fixed file-scope device array instead.  Every GPU holds its own copy of the array at its own address until the
-// process ends; all calls on one GPU share it, so calls that overlap on one GPU race (calls through one model are
-// serialised by the library; two models on one GPU must not run this entry point at the same time).
+// process ends, and all calls on one GPU share it, whichever model or stream they come through.  The library orders
+// them: a per-device host mutex is held while a call's kernels are enqueued, and an event recorded behind a call's
+// last kernel is what the next call's stream waits for before its set-up kernel rewrites the array -- so asynchronous
+// calls on different streams, and calls through different models, run one after the other on the device.  A stream
+// under graph capture can neither wait for an event outside its graph nor record one: calls issued while capturing
+// are ordered only among the nodes of their own graph, and replays of such graphs must not overlap each other or
+// any other user of this entry point on the same GPU.
 namespace {
 
 constexpr int NOALLOC_MAX_UTT = MEL_NOALLOC_MAX_UTT;
@@ -515,6 +520,11 @@ static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
 
 PerDeviceOnce g_scratch_once;
 NoAllocScratch* g_scratch_ptr[PerDeviceOnce::MAX_DEVICES];
+// per device: the last call's "scratch free again" event, whether it has ever been recorded, and the enqueue mutex
+// (created once at set-up, never destroyed: they live as long as the array they guard)
+hipEvent_t g_scratch_free[PerDeviceOnce::MAX_DEVICES];
+bool g_scratch_used[PerDeviceOnce::MAX_DEVICES];
+std::mutex* g_scratch_mu = new std::mutex[PerDeviceOnce::MAX_DEVICES];
 
 struct OffsetsArg {   // utterance boundaries by value in the kernel arguments: no host-to-device copy is needed
     int64_t v[NOALLOC_MAX_UTT + 1];
@@ -559,6 +569,7 @@ void mel_noalloc_init() {
         void* p = nullptr;
         HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         g_scratch_ptr[dev] = (NoAllocScratch*)p;
+        HIP_CHECK(hipEventCreateWithFlags(&g_scratch_free[dev], hipEventDisableTiming));
         HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES));
     });
 }
@@ -590,8 +601,17 @@ void mel_noalloc_run(const MelTables& t, const float* audio_dev, const int64_t* 
     Q3_REQUIRE(tiles <= NOALLOC_MAX_TILES, "mel_noalloc: too much audio for the fixed scratch (at most " +
                                                std::to_string(NOALLOC_MAX_TILES) + " tiles of 32 frames per call)");
     Q3_REQUIRE(t_stride >= tmax, "mel_noalloc: t_stride is smaller than the longest utterance's frame count");
+    std::lock_guard<std::mutex> enqueue(g_scratch_mu[dev]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_CHECK(hipStreamIsCapturing(s, &cap));
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && g_scratch_used[dev]) HIP_CHECK(hipStreamWaitEvent(s, g_scratch_free[dev], 0));   // the previous user has finished
     hipLaunchKernelGGL(mel_noalloc_setup_kernel, dim3(1), dim3(256), 0, s, offs, n_utt, sc);
     HIP_CHECK(hipGetLastError());
     launch_mel(t, audio_dev, sc->off, sc->len, sc->tile_utt, sc->tile_f0, (int)tiles, mel_out_dev, t_stride, sc->dmax, s, bytes);
     launch_mel_normalize(mel_out_dev, n_utt, t_stride, sc->frames, sc->dmax, s);
+    if (!capturing) {
+        HIP_CHECK(hipEventRecord(g_scratch_free[dev], s));
+        g_scratch_used[dev] = true;
+    }
 }

@@ -155,13 +155,13 @@ struct q3asr_model {
     std::map<int, DecodePlan> decode_plans;   // measured plans (tuning runs), per row bucket
     std::set<int> plans_reported;             // buckets whose plan the verbose log has shown
     // Decode of a large group: the attention kernels run on a stream confined to `split_att_cus` compute units and
-    // every other kernel of the step on a stream confined to the remaining ones (created when first needed; a pair
-    // per share that has been asked for, all kept until the model is destroyed).
+    // every other kernel of the step on a stream confined to the remaining ones.  The streams belong to the process
+    // (one set per device and share, created when first needed and kept: see ensure_split_streams); a model only
+    // borrows them.
     hipStream_t stream_att = nullptr, stream_mm = nullptr;
     hipStream_t stream_att2 = nullptr;       // second stream on the attention's CUs (the second half's attention launches)
     int split_att_cus = 0;
     struct SplitStreams { hipStream_t att = nullptr, mm = nullptr, att2 = nullptr; };
-    std::map<int, SplitStreams> split_streams;   // attention CUs -> the streams confined to that share and to the rest
     std::vector<hipEvent_t> chain_events;    // ordering events between the two decode streams
 
     template <class T>
@@ -181,3 +181,5 @@ void model_encode(q3asr_model* m, const float* mel, int t_stride, const int32_t*
 void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* res);
 int model_output_length(const q3asr_config& cfg, int frames);
 int model_decode_att_cus(const q3asr_model* m, int n_utt);
+// Destroys the process's CU-confined decode streams (the library's exit handler, after the last model is gone).
+void model_release_process_streams();

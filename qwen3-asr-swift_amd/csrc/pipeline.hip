@@ -538,23 +538,37 @@ bool trace_on() {
 }
 #define Q3_TRACE(...) do { if (trace_on()) { fprintf(stderr, "[q3asr] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
-// The two CU-confined streams for a share of the device.  A model keeps every pair it has created until it is
-// destroyed: a queue with a CU mask that is destroyed and re-created under another mask while the model's ordering
-// events still refer to its last commands was followed by a call that never returned (seen once in a test that
-// changes the share between calls).
-void ensure_split_streams(q3asr_model* m, int att_cus) {
-    if (m->stream_att && m->split_att_cus == att_cus) return;
-    auto& st = m->split_streams[att_cus];
+// The CU-confined streams for a share of a device.  They belong to the process, not to a model, and live until the
+// process ends: the runtime does not give a destroyed CU-masked queue's slot back, and the 17th
+// hipExtStreamCreateWithCUMask of a process that has destroyed 16 such streams never returns (measured with the
+// decode loop's event chain on two masked streams, destroyed and re-created under another mask between rounds:
+// `scripts/probe_cu_mask.hip chain`; with the streams kept the same loop runs on).  A process that loads and unloads
+// models all day (or a test run) therefore must not create streams per model.  Models on one device share them; calls
+// of different models then queue behind one another on these streams, each ordered by its own events.
+struct SplitStreamCache {
+    std::mutex mu;
+    std::map<std::pair<int, int>, q3asr_model::SplitStreams> by_share;   // (device, attention CUs)
+};
+SplitStreamCache& split_stream_cache() {
+    static SplitStreamCache* c = new SplitStreamCache();   // never destructed: no HIP call from a static destructor
+    return *c;
+}
+
+void ensure_split_streams(q3asr_model* m, int att_cus, bool second_att_stream) {
+    SplitStreamCache& cache = split_stream_cache();
+    std::lock_guard<std::mutex> lk(cache.mu);
+    auto& st = cache.by_share[{m->device, att_cus}];
+    const int cus = device_cus(), words = (cus + 31) / 32;
+    std::vector<uint32_t> ma(words, 0), mb(words, 0);
+    for (int i = 0; i < cus; ++i) (i < att_cus ? ma : mb)[i >> 5] |= 1u << (i & 31);
     if (!st.att) {
         Q3_TRACE("split streams: creating the streams for %d attention CUs", att_cus);
-        const int cus = device_cus(), words = (cus + 31) / 32;
         Q3_REQUIRE(cus % 8 == 0 && att_cus % 8 == 0 && att_cus >= 8 && cus - att_cus >= 8, "decode: bad compute-unit split");
-        std::vector<uint32_t> ma(words, 0), mb(words, 0);
-        for (int i = 0; i < cus; ++i) (i < att_cus ? ma : mb)[i >> 5] |= 1u << (i & 31);
+        Q3_REQUIRE(cache.by_share.size() <= 4, "decode: more than four different compute-unit shares asked for in one process");
         HIP_CHECK(hipExtStreamCreateWithCUMask(&st.att, (uint32_t)words, ma.data()));
-        HIP_CHECK(hipExtStreamCreateWithCUMask(&st.att2, (uint32_t)words, ma.data()));
         HIP_CHECK(hipExtStreamCreateWithCUMask(&st.mm, (uint32_t)words, mb.data()));
     }
+    if (second_att_stream && !st.att2) HIP_CHECK(hipExtStreamCreateWithCUMask(&st.att2, (uint32_t)words, ma.data()));
     m->stream_att = st.att;
     m->stream_att2 = st.att2;
     m->stream_mm = st.mm;
@@ -672,7 +686,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
     }
     auto head_tile_for = [&](int rows) {  // 256x256 once the rows fill more than half of the tile
         int t = gemm_pick_tile(rows, cfg.vocab);
-        if (t == 1 || (t == 3 && (wf != W_BF16 || (rows <= 128 && !getenv("Q3ASR_FORCE_TILE"))))) t = 0;
+        if (t == 1 || (t == 3 && (wf != W_BF16 || (rows <= 128 && q3_knobs().force_tile < 0)))) t = 0;
         return t;
     };
     const int max_parts = gemm_argmax_parts(cfg.vocab, 1);  // the narrowest tile writes the most partials
@@ -807,12 +821,12 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         const int mm_cus = att_cus ? device_cus() - att_cus : 0;
         int n_half = att_cus ? 2 : 1;
         const bool was_split = n_half == 2;
-        if (was_split) ensure_split_streams(m, att_cus);
         bool chain = was_split;   // attention and the other kernels are on different streams
         // The halves' attention launches on one stream or on two (both confined to the attention's CUs): on two, a
         // launch starts filling CUs while the other half's previous launch drains, instead of ~11 us after its end.
         const char* env_as = getenv("Q3ASR_ATT_STREAMS");
         const int att_streams = was_split && env_as && atoi(env_as) == 2 ? 2 : 1;
+        if (was_split) ensure_split_streams(m, att_cus, att_streams == 2);
         // The reference computes nothing for a clip once it has stopped (:571-574).  Here a stopped utterance is skipped by
         // the attention kernel at once (its done flag) and leaves the step's rows at the next poll: the step kernel
         // writes the list of utterances still running, and switching the row -> utterance map to that list shrinks
@@ -1272,3 +1286,14 @@ void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* re
 }
 
 int model_decode_att_cus(const q3asr_model* m, int n_utt) { return decode_att_cus(m, n_utt); }
+
+void model_release_process_streams() {
+    SplitStreamCache& cache = split_stream_cache();
+    std::lock_guard<std::mutex> lk(cache.mu);
+    for (auto& kv : cache.by_share) {
+        (void)hipSetDevice(kv.first.first);
+        for (hipStream_t s : {kv.second.att, kv.second.att2, kv.second.mm})
+            if (s) (void)hipStreamDestroy(s);
+    }
+    cache.by_share.clear();
+}

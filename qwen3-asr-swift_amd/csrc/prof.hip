@@ -17,8 +17,10 @@ struct State {
     size_t used = 0;
     ~State() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
-std::mutex g_mu;
-std::map<hipStream_t, std::shared_ptr<State>> g_by_stream;
+// Never destructed: a profile left running at process exit must not have its events destroyed from a static
+// destructor, after the HIP runtime's own exit handlers (a model's destruction stops its profile).
+std::mutex& g_mu = *new std::mutex();
+std::map<hipStream_t, std::shared_ptr<State>>& g_by_stream = *new std::map<hipStream_t, std::shared_ptr<State>>();
 std::atomic<int> g_running{0};   // profiles in progress: the launchers' fast path when none is
 
 std::shared_ptr<State> find(hipStream_t s) {

@@ -110,6 +110,11 @@ LinearW build_linear(q3asr_model* m, const std::vector<RowRef>& rows, int64_t K,
         L.biases = upload_vec(m, bbuf);
         L.fmt = W_Q4;
     }
+    // every checkpoint tensor feeds exactly one operand: its host copy is released as soon as that operand is on the
+    // device, so a model being loaded never holds much more than one layer twice (a finalize that fails half-way
+    // leaves a model that cannot be finalized again; it could not have been used anyway)
+    for (auto& kv : nrows)
+        for (const char* part : {".weight", ".scales", ".biases"}) m->host.erase(kv.first + part);
     return L;
 }
 

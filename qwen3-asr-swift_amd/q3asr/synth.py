@@ -35,8 +35,12 @@ def _quantize_q4(w, group):
     return packed, to_bf16_bits(scale), to_bf16_bits(bias)
 
 
-def make_checkpoint(cfg, seed=0, std=0.02, q4=None):
-    """Random checkpoint for a Q3Config.  q4 defaults to cfg.weight_format == 1."""
+def make_checkpoint(cfg, seed=0, std=0.02, q4=None, workers=0):
+    """Random checkpoint for a Q3Config.  q4 defaults to cfg.weight_format == 1.  workers > 0: the tensors are drawn
+    and converted on that many threads from per-tensor generators (other values than the sequential default, same
+    distributions: for benchmarks, where drawing 1.7 billion parameters on one core takes most of a minute)."""
+    if workers > 0:
+        return _make_checkpoint_threaded(cfg, seed, std, q4, workers)
     rng = np.random.default_rng(seed)
     q4 = bool(cfg.weight_format) if q4 is None else q4
     ck = {}
@@ -96,6 +100,83 @@ def make_checkpoint(cfg, seed=0, std=0.02, q4=None):
         linear(p + "mlp.gate_proj", cfg.inter, h, False, q4, 1.0 / np.sqrt(h))
         linear(p + "mlp.up_proj", cfg.inter, h, False, q4, 1.0 / np.sqrt(h))
         linear(p + "mlp.down_proj", h, cfg.inter, False, q4, 1.0 / np.sqrt(cfg.inter))
+    return ck
+
+
+def _make_checkpoint_threaded(cfg, seed, std, q4, workers):
+    """make_checkpoint with every tensor's draw, scaling and conversion as one task on a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    q4 = bool(cfg.weight_format) if q4 is None else q4
+    tasks = []          # (names, function of a generator -> tuple of (array, tag))
+
+    def dense(name, shape, s=std):
+        tasks.append(((name,), lambda g: ((to_bf16_bits(g.standard_normal(shape, dtype=f32) * f32(s)), "bf16"),)))
+
+    def norm_w(name, n):
+        tasks.append(((name,), lambda g: ((to_bf16_bits(f32(1.0) + g.standard_normal(n, dtype=f32) * f32(0.05)), "bf16"),)))
+
+    def linear(name, out, inp, bias, quant=False, s=std):
+        if quant:
+            def job(g):
+                p, sc, bi = _quantize_q4(g.standard_normal((out, inp), dtype=f32) * f32(s), cfg.group_size)
+                return (p, "u32"), (sc, "bf16"), (bi, "bf16")
+            tasks.append(((name + ".weight", name + ".scales", name + ".biases"), job))
+        else:
+            dense(name + ".weight", (out, inp), s)
+        if bias:
+            dense(name + ".bias", (out,))
+
+    a, d, c = "audio_tower.", cfg.enc_d_model, cfg.conv_channels
+    f3 = (((cfg.n_mels + 1) // 2 + 1) // 2 + 1) // 2
+    dense(a + "conv2d1.weight", (c, 3, 3, 1), 0.3)
+    dense(a + "conv2d1.bias", (c,))
+    for n in ("conv2d2", "conv2d3"):
+        dense(a + n + ".weight", (c, 3, 3, c), 1.0 / np.sqrt(9 * c))
+        dense(a + n + ".bias", (c,))
+    dense(a + "conv_out.weight", (d, c * f3), 1.0 / np.sqrt(c * f3))
+    for i in range(cfg.enc_layers):
+        p = f"{a}layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            linear(p + "self_attn." + n, d, d, True, s=1.0 / np.sqrt(d))
+        linear(p + "fc1", cfg.enc_ffn, d, True, s=1.0 / np.sqrt(d))
+        linear(p + "fc2", d, cfg.enc_ffn, True, s=1.0 / np.sqrt(cfg.enc_ffn))
+        for n in ("self_attn_layer_norm", "final_layer_norm"):
+            norm_w(p + n + ".weight", d)
+            dense(p + n + ".bias", (d,))
+    norm_w(a + "ln_post.weight", d)
+    dense(a + "ln_post.bias", (d,))
+    linear(a + "proj1", d, d, True, s=1.0 / np.sqrt(d))
+    linear(a + "proj2", cfg.enc_out_dim, d, True, s=1.0 / np.sqrt(d))
+    h, hd = cfg.hidden, cfg.head_dim
+    # the embedding is the largest tensor by far: drawn in row blocks so that it does not end up as one thread's task
+    eblocks = [(r, min(r + 8192, cfg.vocab)) for r in range(0, cfg.vocab, 8192)]
+    if q4:
+        linear("model.embed_tokens", cfg.vocab, h, False, quant=True)
+    else:
+        for r0, r1 in eblocks:
+            dense(f"model.embed_tokens.weight#{r0}", (r1 - r0, h))
+    norm_w("model.norm.weight", h)
+    for i in range(cfg.layers):
+        p = f"model.layers.{i}."
+        linear(p + "self_attn.q_proj", cfg.heads * hd, h, False, q4, 1.0 / np.sqrt(h))
+        linear(p + "self_attn.k_proj", cfg.kv_heads * hd, h, False, q4, 1.0 / np.sqrt(h))
+        linear(p + "self_attn.v_proj", cfg.kv_heads * hd, h, False, q4, 1.0 / np.sqrt(h))
+        linear(p + "self_attn.o_proj", h, cfg.heads * hd, False, q4, 1.0 / np.sqrt(cfg.heads * hd))
+        norm_w(p + "self_attn.q_norm.weight", hd)
+        norm_w(p + "self_attn.k_norm.weight", hd)
+        norm_w(p + "input_layernorm.weight", h)
+        norm_w(p + "post_attention_layernorm.weight", h)
+        linear(p + "mlp.gate_proj", cfg.inter, h, False, q4, 1.0 / np.sqrt(h))
+        linear(p + "mlp.up_proj", cfg.inter, h, False, q4, 1.0 / np.sqrt(h))
+        linear(p + "mlp.down_proj", h, cfg.inter, False, q4, 1.0 / np.sqrt(cfg.inter))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        futs = [pool.submit(job, np.random.default_rng((seed, k))) for k, (_, job) in enumerate(tasks)]
+        ck = {}
+        for (names, _), fut in zip(tasks, futs):
+            for name, val in zip(names, fut.result()):
+                ck[name] = val
+    if not q4:
+        ck["model.embed_tokens.weight"] = (np.concatenate([ck.pop(f"model.embed_tokens.weight#{r0}")[0] for r0, _ in eblocks]), "bf16")
     return ck
 
 

@@ -1,5 +1,7 @@
 // Probe for CU-masked streams on MI355X: (1) which (XCC, SE, CU) a mask bit selects, (2) streaming-read bandwidth
-// against the number of CUs a stream may use, (3) the same read stream beside an MFMA-bound kernel on the other CUs.
+// against the number of CUs a stream may use, (3) the same read stream beside an MFMA-bound kernel on the other CUs,
+// (4) "chain": the decode loop's event chain between two masked streams, with the streams destroyed and re-created
+// under another mask between rounds while the events live on.
 // Build: hipcc -O3 --offload-arch=gfx950 scripts/probe_cu_mask.hip -o gpurun_out/probe_cu_mask
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -163,6 +165,66 @@ __global__ __launch_bounds__(512) void mfma_kernel(float* out, int iters) {
     if (s == 12345.f) out[0] = s;
 }
 
+__global__ void tick_kernel(int* p, int spin) {
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(20);
+    if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1;
+}
+
+#include <csignal>
+#include <unistd.h>
+static volatile int g_round = -1, g_iter = -1, g_phase = 0;
+static void on_alarm(int) {
+    char b[128];
+    int n = snprintf(b, sizeof b, "STALLED in round %d, iteration %d, phase %d\n", g_round, g_iter, g_phase);
+    (void)!write(1, b, n);
+    _exit(3);
+}
+
+// The decode loop's pattern: a plain stream s0 forks two masked streams A and M; per iteration M records "pre", A
+// waits for it, runs, records "attn", M waits for it and runs; every 8th iteration M copies a word to pageable host
+// memory and is synchronised; at the end both join s0.  Between rounds A and M are destroyed and re-created with the
+// other share while the events (last recorded on the destroyed streams) are kept, as a model did that was asked for
+// another share.  keep = 1: the streams of both shares are created once and kept instead.
+static int chain_probe(int rounds, int keep) {
+    signal(SIGALRM, on_alarm);
+    const int layers = 28, shares[2] = {160, 64};
+    hipStream_t s0; CK(hipStreamCreate(&s0));
+    std::vector<hipEvent_t> ev(2 * layers + 2);
+    for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int* d; CK(hipMalloc(&d, 64)); CK(hipMemset(d, 0, 64));
+    auto mk = [&](int lo, int hi) { std::vector<uint32_t> m(8, 0); for (int i = lo; i < hi; ++i) m[i >> 5] |= 1u << (i & 31);
+                                    hipStream_t s; CK(hipExtStreamCreateWithCUMask(&s, 8, m.data())); return s; };
+    hipStream_t kept[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    for (int r = 0; r < rounds; ++r) {
+        g_round = r; g_iter = -1; g_phase = 1; alarm(20);
+        const int sh = shares[r & 1];
+        hipStream_t A, M;
+        if (keep) { if (!kept[r & 1][0]) { kept[r & 1][0] = mk(0, sh); kept[r & 1][1] = mk(sh, 256); } A = kept[r & 1][0]; M = kept[r & 1][1]; }
+        else { A = mk(0, sh); M = mk(sh, 256); }
+        g_phase = 2;
+        CK(hipEventRecord(ev[2 * layers], s0)); CK(hipStreamWaitEvent(A, ev[2 * layers], 0)); CK(hipStreamWaitEvent(M, ev[2 * layers], 0));
+        int host = 0;
+        for (int it = 1; it <= 24; ++it) {
+            g_iter = it;
+            for (int l = 0; l < layers; ++l) {
+                hipLaunchKernelGGL(tick_kernel, dim3(8), dim3(64), 0, M, d + 1, 2); CK(hipEventRecord(ev[l], M));
+                CK(hipStreamWaitEvent(A, ev[l], 0)); hipLaunchKernelGGL(tick_kernel, dim3(8), dim3(64), 0, A, d + 2, 2); CK(hipEventRecord(ev[layers + l], A));
+                CK(hipStreamWaitEvent(M, ev[layers + l], 0)); hipLaunchKernelGGL(tick_kernel, dim3(8), dim3(64), 0, M, d, 2);
+            }
+            if (it % 8 == 0) { g_phase = 3; CK(hipMemcpyAsync(&host, d, 4, hipMemcpyDeviceToHost, M)); CK(hipStreamSynchronize(M)); g_phase = 2; }
+        }
+        g_phase = 4;
+        CK(hipEventRecord(ev[2 * layers + 1], M)); CK(hipStreamWaitEvent(s0, ev[2 * layers + 1], 0));
+        CK(hipEventRecord(ev[2 * layers + 1], A)); CK(hipStreamWaitEvent(s0, ev[2 * layers + 1], 0));
+        CK(hipStreamSynchronize(s0));
+        g_phase = 5;
+        if (!keep) { CK(hipStreamDestroy(A)); CK(hipStreamDestroy(M)); }
+        printf("round %d (share %d, %s): %d ticks\n", r, sh, keep ? "streams kept" : "streams destroyed afterwards", host);
+    }
+    alarm(0);
+    return 0;
+}
+
 static hipStream_t masked_stream(const std::vector<int>& bits) {
     std::vector<uint32_t> mask(8, 0);
     for (int b : bits) mask[b >> 5] |= 1u << (b & 31);
@@ -191,6 +253,7 @@ int main(int argc, char** argv) {
         printf("masked stream: %s\n", hipGetErrorString(e));
         return 0;
     }
+    if (argc >= 3 && !strcmp(argv[1], "chain")) return chain_probe(atoi(argv[2]), argc >= 4 ? atoi(argv[3]) : 0);   // chain <rounds> [keep]
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;

@@ -160,3 +160,26 @@ def test_greedy_stop_rules_on_device(tiny_model):
             assert got[i] == _rules_reference(picks[i], bool(seen0[i]), max_tokens), (i, max_tokens)
     free = m.op_greedy_rules(picks, seen0, max_tokens=100, stop_rules=False)
     assert all(len(t) == 100 for t in free)
+
+
+def test_gelu_epilogue_against_exact_erf(tiny_model):
+    """The GEMM epilogue's GELU (conv2 / conv3 / fc1 / proj1 of the encoder) on a sweep of bf16 inputs over [-8, 8]
+    against 0.5 x (1 + erf(x / sqrt 2)) in float64 (AudioEncoder.swift:379-384, 127-129): within 1e-6 absolute everywhere,
+    and within one bf16 step (2^-8 relative) down to x = -5.5, below which the value is under 1.1e-7.  The input rides in
+    as a weight column against an activation of one, so the product is exact and the epilogue alone is measured."""
+    from scipy.special import erfc
+    m = tiny_model[0]
+    xs = bf16_vals(bf16_bits(np.concatenate([np.linspace(-8, 8, 3201), -np.logspace(-3, 0.9, 400), np.logspace(-3, 0.9, 400)])))
+    N = (len(xs) + 3) // 4 * 4
+    w = np.zeros((N, 32), dtype=np.float32)
+    w[:len(xs), 0] = xs
+    a = np.zeros((16, 32), dtype=np.float32)
+    a[:, 0] = 1.0
+    got = m.op_gemm(bf16_bits(a), bf16_bits(w), gelu=True, tile=1)[0, :len(xs)].astype(np.float64)
+    x64 = xs.astype(np.float64)
+    want = 0.5 * x64 * erfc(-x64 / np.sqrt(2.0))
+    assert np.abs(got - want).max() <= 1e-6
+    near = x64 >= -5.5
+    rel = np.abs(got - want)[near] / np.maximum(np.abs(want[near]), 1e-300)
+    assert rel[want[near] != 0].max() <= 2.0 ** -8
+    assert np.abs(got[~near]).max() <= 1.5e-7

@@ -264,7 +264,33 @@ def test_bench_launcher_starts_one_rank_per_gpu(tmp_path):
     assert seen[0]["env"]["MASTER_PORT"] == seen[1]["env"]["MASTER_PORT"] and seen[0]["env"]["MASTER_ADDR"] == "127.0.0.1"
     assert all(s["argv"] == ["--gpus", "2", "--steps", "1"] for s in seen)
     run = subprocess.run([sys.executable, "-c", driver % (["--fail"],)], capture_output=True, text=True, timeout=120)
-    assert run.returncode != 0 and "ranks failed" in run.stderr
+    assert run.returncode != 0 and "rank 1 ended with exit code 3" in run.stderr
+
+
+def test_bench_launcher_ends_the_job_when_one_rank_dies(tmp_path):
+    """A rank that dies (out of memory, bad device ordinal) while its siblings sit in a collective: the launcher stops
+    the siblings and returns non-zero within seconds, without rank 0's line -- instead of waiting for the backend's
+    timeout or the driver's limit."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, time, signal\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    time.sleep(0.5); sys.exit(3)\n"
+        "if os.environ['RANK'] == '2':\n"
+        "    signal.signal(signal.SIGTERM, signal.SIG_IGN)     # a rank stuck so deep that it ignores the request to stop\n"
+        "print('{\"n_gpus\": 3}', flush=True)\n"
+        "time.sleep(600)\n")
+    driver = ("import sys; sys.path.insert(0, %r); import bench; bench.spawn_ranks(3, [], child=[sys.executable, %r], grace_s=2.0)" % (root, str(child)))
+    t0 = time.monotonic()
+    run = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, timeout=60)
+    took = time.monotonic() - t0
+    assert run.returncode != 0 and "rank 1 ended with exit code 3" in run.stderr
+    assert took < 10.0, took
+    assert run.stdout.strip() == ""                      # a partial job prints no result line
 
 
 def test_config_json_fields_the_reference_reads():
