@@ -30,19 +30,38 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 
-def cpu_baseline(cfg, ck, audio, decode_steps):
+def host_cpu_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(cfg, ck, audio, decode_steps, sample_rate=16000, what="1 clip x 30 s, 1.7B dims"):
     """CPU restatement of the reference algorithm (numpy fp32; NOT the reference's Swift/MLX build,
     which cannot be produced here), timed on this box's host cores on one clip of the same workload.
     Decode is timed for `decode_steps` greedy steps; the remaining steps of the 448 tokens the GPU run executes are
-    charged by a linear fit of the measured per-step time over the growing context."""
+    charged by a linear fit of the measured per-step time over the growing context.  Beside it, the reference
+    frontend's own arithmetic -- a direct DFT per frame and bin on one thread (AudioPreprocessing.swift:184-240) --
+    is timed through its plain-C restatement (oracle/mel_direct.c)."""
     import oracle
     from q3asr import oracle_cfgs, synth
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(threads, int(os.environ.get("OMP_NUM_THREADS", threads)))
     w = synth.checkpoint_to_f32(ck)
     enc_cfg, dec_cfg = oracle_cfgs(cfg)
+    try:
+        a16 = oracle.mel.resample_linear(audio, sample_rate, 16000) if sample_rate != 16000 else audio
+        _, direct_s = oracle.mel.extract_features_c(a16[:480000])
+        direct = f"; the reference's direct-DFT log-mel alone, plain C on one thread: {direct_s:.2f} s"
+    except (RuntimeError, OSError) as e:
+        direct = f"; (direct-DFT C restatement not timed: {e})"
     t0 = time.perf_counter()
-    feats = oracle.mel.process(audio, 16000)
+    feats = oracle.mel.process(audio, sample_rate)
     t1 = time.perf_counter()
     a = oracle.encoder.encode(feats, w, enc_cfg)
     t2 = time.perf_counter()
@@ -66,13 +85,53 @@ def cpu_baseline(cfg, ck, audio, decode_steps):
     rest = np.arange(decode_steps + 1, 448, dtype=np.float64)
     decode_total = float(np.sum(per)) + float(np.sum(c0 + max(c1, 0.0) * rest))
     total = (t1 - t0) + (t2 - t1) + (t4 - t3) + decode_total
+    seconds = min(len(audio) / float(sample_rate), 30.0)        # the reference drops what follows 30 s
     return {
-        "value": round(len(audio) / 16000.0 / total, 4), "unit": "RTFx (audio s per wall s)", "cores": threads, "kind": "port",
-        "sample": f"1 clip x 30 s, 1.7B dims, numpy fp32 restatement: mel {t1 - t0:.2f} s + encoder {t2 - t1:.2f} s + prefill "
+        "value": round(seconds / total, 4), "unit": "RTFx (audio s per wall s)", "cores": threads, "kind": "port",
+        "sample": f"{what}, numpy fp32 restatement of the reference algorithm (not its Swift/MLX build) on {host_cpu_name()}, {threads} threads: "
+                  f"mel {t1 - t0:.2f} s + encoder {t2 - t1:.2f} s + prefill "
                   f"{t4 - t3:.2f} s + {decode_steps} decode steps {sum(per):.2f} s measured; steps {decode_steps + 1}-447 from a linear fit "
                   f"of the measured per-step times over the context length ({c0 * 1e3:.1f} ms + {max(c1, 0.0) * 1e6:.1f} us per cached token): "
-                  f"{decode_total:.2f} s of decode in all",
+                  f"{decode_total:.2f} s of decode in all" + direct,
+        "stage_seconds": {"mel": round(t1 - t0, 3), "encoder": round(t2 - t1, 3), "prefill": round(t4 - t3, 3), "decode": round(decode_total, 3)},
     }
+
+
+def run_c1(args, emit):
+    """The reference's own way of running (CLI transcribe, main.swift:297-315): the 20 s test clip, loaded at 24 kHz,
+    one utterance, 0.6B dimensions -- the GPU's batch-1 call beside the CPU restatement, stage by stage."""
+    import torch
+    from q3asr import Qwen3ASRModel, make_config, synth
+    from q3asr.audio_io import load_wav
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libq3asr has no CPU path")
+    audio, rate = load_wav(os.path.join(ROOT, "tests", "golden", "test_audio.wav"))
+    cfg = make_config("0.6b", max_batch=1, weight_format=1 if args.weights == "q4" else 0)
+    ck = synth.make_checkpoint(cfg, seed=0, workers=8)
+    model = Qwen3ASRModel.from_checkpoint(cfg, ck, device=0)
+    run = lambda: model.transcribe_batch([audio], rate, max_tokens=args.max_tokens, stop_rules=not args.no_stop_rules)
+    for _ in range(max(1, args.warmup)):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [run() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ms = {k: round(sum(o.ms[k] for o in outs) / args.steps, 2) for k in outs[0].ms}
+    model.close()
+    seconds = len(audio) / float(rate)
+    line = {"metric": f"RTFx (audio s per wall s), 0.6B {args.weights}, the reference's test clip, batch 1", "value": round(seconds / dt, 2),
+            "unit": "x real-time", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": round(dt * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "tests/golden/test_audio.wav (the "
+            "reference's Tests/Qwen3ASRTests/Resources/test_audio.wav: 20.0 s, 24 kHz mono), seeded random weights",
+            "config": {"workload": f"c1: one utterance, the whole call from host samples at {rate} Hz to host token ids (resample, log-mel, encoder, "
+                                   f"prefill, {outs[0].tokens_total} greedy tokens), Qwen3-ASR-0.6b {args.weights}",
+                       "tokens_per_clip": outs[0].tokens_total, "stage_ms_per_step_rank0": ms},
+            "roofline": None}
+    line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(cfg, ck, audio, args.cpu_decode_steps, sample_rate=rate,
+                                                                          what="the same clip (20 s at 24 kHz), 0.6B dims, batch 1")
+    emit(line)
+    return 0
 
 
 def pmc_traffic(kernel, args):
@@ -208,8 +267,8 @@ def main():
                     "through it -- the RCCL calls of a multi-GPU run, on a box with one GPU")
     ap.add_argument("--leak-model", action="store_true", help="diagnostic: end the process without q3asr_destroy, like a host whose "
                     "finaliser never runs (the library's own exit handler then has to release the model)")
-    ap.add_argument("--workload", default="transcribe", choices=["transcribe", "mel", "ragged"],
-                    help="transcribe: the headline run, --batch clips of --clip-seconds per GPU.  mel: the log-mel frontend alone on the "
+    ap.add_argument("--workload", default="transcribe", choices=["transcribe", "mel", "ragged", "c1"],
+                    help="c1: the reference's test clip through the 0.6B model, one utterance, GPU beside the CPU restatement.  transcribe: the headline run, --batch clips of --clip-seconds per GPU.  mel: the log-mel frontend alone on the "
                          "same clips (device buffers in and out).  ragged: --utterances recordings per GPU with durations U[5, 300] s "
                          "(seed 4321), cut into pieces of at most 30 s, cost-sharded over the ranks, length-bucketed by the library")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "q4"], help="q4: MLX affine 4-bit group-quantised decoder weights")
@@ -230,6 +289,9 @@ def main():
 
     def emit(line):
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    if args.workload == "c1":
+        raise SystemExit(run_c1(args, emit))
 
     import datetime
     import torch

@@ -147,3 +147,28 @@ def process(audio, sample_rate, mode="exact"):
     if sample_rate != SAMPLE_RATE:
         audio = resample_linear(audio, sample_rate, SAMPLE_RATE)
     return extract_features(audio, mode)
+
+
+def extract_features_c(audio):
+    """The same stage through oracle/mel_direct.c: the reference's loops (direct DFT per frame and bin, twiddle rows
+    copied per dot product, scalar mel product) in plain C on one thread -- AudioPreprocessing.swift:131-324.
+    Returns ([128, T] fp32, seconds spent inside the C function)."""
+    import ctypes
+    import os
+    import time
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libq3oracle.so")
+    if not os.path.exists(so):
+        raise RuntimeError("oracle/libq3oracle.so is missing: run `make -C oracle` (build() does)")
+    lib = ctypes.CDLL(so)
+    lib.q3oracle_mel_direct.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_int)]
+    audio = np.ascontiguousarray(audio, dtype=f32)
+    fb = np.ascontiguousarray(mel_filterbank(), dtype=f32)
+    out = np.zeros((N_MELS, MAX_FRAMES), dtype=f32)
+    t = ctypes.c_int(0)
+    t0 = time.perf_counter()
+    rc = lib.q3oracle_mel_direct(audio.ctypes.data, len(audio), fb.ctypes.data, out.ctypes.data, MAX_FRAMES, ctypes.byref(t))
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError("q3oracle_mel_direct failed")
+    return np.ascontiguousarray(out[:, :t.value]), dt

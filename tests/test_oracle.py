@@ -227,3 +227,23 @@ def test_stop_rules():
     assert len(toks) == 65                                                 # first length whose last 64 exclude the tag
     assert oracle.generate.post_process("language English<asr_text> hello <asr_text> world ") == "world"
     assert oracle.generate.post_process("no tag") == "no tag"
+
+
+def test_c_restatement_of_the_direct_dft_agrees_with_the_numpy_one():
+    """oracle/mel_direct.c (the reference's loops in plain C, timed as the reference frontend's own cost) against
+    the numpy restatement's "literal" mode on the reference's test clip: two evaluations of the same fp32 arithmetic in
+    different summation orders and with different libm cos / sin.  The literal twiddle angle -2 pi k n / 400 in fp32
+    carries an error of 4e-3 rad at k n = 80 000, which the two libm then turn into table values that may differ in the
+    last bits, so the bound is the one the GPU test uses for the literal form: 4e-3 at worst, 4e-5 on average."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    audio, rate = read_wav_pcm16(os.path.join(GOLDEN, "test_audio.wav"))
+    a16 = oracle.mel.resample_linear(audio, rate, 16000)[80000:112000]      # 2 s of the spoken part
+    got, seconds = oracle.mel.extract_features_c(a16)
+    want = oracle.mel.extract_features(a16, "literal")
+    assert got.shape == want.shape == (128, 200)
+    d = np.abs(got - want)
+    assert d.max() <= 4e-3 and d.mean() <= 4e-5
+    assert np.abs(got - oracle.mel.extract_features(a16, "exact")).max() <= 5e-3
+    assert seconds > 0
