@@ -272,7 +272,8 @@ def main():
                          "same clips (device buffers in and out).  ragged: --utterances recordings per GPU with durations U[5, 300] s "
                          "(seed 4321), cut into pieces of at most 30 s, cost-sharded over the ranks, length-bucketed by the library")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "q4"], help="q4: MLX affine 4-bit group-quantised decoder weights")
-    ap.add_argument("--audio", default="speechlike", choices=["speechlike", "noise"])
+    ap.add_argument("--audio", default="speechlike", choices=["speechlike", "noise", "gapped"],
+                    help="gapped: speech-like with a quarter of every clip digitally silent (the log-mel clamp then has work to do)")
     ap.add_argument("--utterances", type=int, default=256, help="ragged workload: recordings per GPU")
     ap.add_argument("--length-dist", default="none", help="none: every clip decodes until the stop rules or max_tokens end it (with "
                     "random weights: max_tokens).  uLO-HI[+straggler]: scripted lengths -- clip u stops on an EOS after U[LO, HI] tokens "

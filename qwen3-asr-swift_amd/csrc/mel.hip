@@ -13,9 +13,15 @@
 // tile's arithmetic); phase 1 windows the samples and runs the 800 radix-8 butterflies; phase 2 the 256 25-point transforms;
 // phase 3 untangles the 101 bin pairs of every frame into power values; phase 4 applies the slaney filterbank with
 // compile-time filter supports, log10, the per-utterance running maximum (wave reduction + one atomic per wave) and stores
-// [mel][frame] rows, 32 consecutive frames per store.  Output is the raw log10 mel; the max-8 clamp and (x+4)/4 scale need the
-// utterance-wide maximum and are applied by the consumer (conv1) or by launch_mel_normalize for callers that want the
-// reference's exact output tensor.  Twiddles are rounded from double; the window multiplies the samples in fp32 as the
+// [mel][frame] rows, 32 consecutive frames per store.  The max-8 clamp needs the utterance-wide maximum.  Inside the
+// transcription pipeline the rows are stored raw and the consumer (conv1) clamps and scales them.  For callers that want
+// the reference's exact output tensor the rows are stored already scaled, (y + 4) / 4, and the kernel also keeps each
+// utterance's minimum: the clamp only changes values more than eight decades under the utterance's peak (digital silence,
+// the near-DC filters of a clean signal), so launch_mel_clamp afterwards leaves at once for every utterance whose minimum
+// is above the floor and rewrites only the 16-byte pieces that hold a value below it elsewhere.  (Minima per group of 16
+// mel rows, so that the clamp could skip most rows of the other utterances too, were measured: the eight extra wave
+// reductions per tile cost the log-mel kernel more, 2.06 -> 2.38 ms per 1024 clips, than the clamp saves.)  x -> (x + 4) / 4 is monotonic in fp32, so
+// clamping the scaled value to the scaled floor gives the bits of scaling the clamped value.  Twiddles are rounded from double; the window multiplies the samples in fp32 as the
 // reference does (:161-164, 195-197).
 #include "mel.h"
 #include "prof.h"
@@ -117,7 +123,8 @@ struct MelTileOut {
     int n_store;         // how many of the lane's four frames are returned (0..4)
     int n_max;           // how many of them count for the running maximum
     bool vec;            // 16-byte stores allowed
-    float vmax;
+    bool scaled;         // store (y + 4) / 4 instead of y and keep the minimum of what is stored
+    float vmax, vmin;
 };
 
 // One column tile: CT = tile, OFF = position of its first weight fragment in the wave's register-resident list.
@@ -132,8 +139,13 @@ __device__ __forceinline__ void mel_col_tile(const float* pw, const float (&bf)[
     float y[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+#pragma clang fp contract(off)   // log10 is rounded before the scale touches it, exactly as when it is stored raw and scaled by its consumer
         y[r] = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
         if (r < o.n_max) o.vmax = fmaxf(o.vmax, y[r]);
+        if (o.scaled) {
+            if (r < o.n_store) o.vmin = fminf(o.vmin, y[r]);
+            y[r] = (y[r] + 4.0f) * 0.25f;    // AudioPreprocessing.swift:286-288
+        }
     }
     float* dst = o.out + (int64_t)(16 * CT + n) * o.t_stride;
     if (o.vec && o.n_store == 4) {
@@ -202,7 +214,8 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
                                                              const int* __restrict__ tile_f0, int n_tiles,
                                                              const float* __restrict__ tables,
                                                              const float* __restrict__ fb_frags, float* __restrict__ out,
-                                                             int t_stride, unsigned* __restrict__ d_max, int vec_ok) {
+                                                             int t_stride, unsigned* __restrict__ d_max, int vec_ok,
+                                                             unsigned* __restrict__ d_min) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* xs = sm;                           // samples of the tile; from phase 3 on the power rows [32][201]
     cpx* zc = (cpx*)(sm + XS_N);              // transform values [32][200], (re, im) pairs
@@ -331,7 +344,9 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
             // running maximum over every frame the reference computes, the dropped last one included (:269-270)
             o.n_max = min(max(frames_total - frame0, 0), 4);
             o.vec = vec_ok;
+            o.scaled = d_min != nullptr;
             o.vmax = -INFINITY;
+            o.vmin = INFINITY;
             const float* pw = xs + (16 * rt + n) * POW_STRIDE + g;   // A operand: row = frame, k = bin
             if (wave < 2) {
                 mel_col_tile<7, 0>(pw, bf, n, o);
@@ -346,6 +361,10 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
             }
             const float vmax = wave_max(o.vmax);
             if (lane == 0 && vmax > -INFINITY) atomicMax(d_max + cur.u, enc_max(vmax));
+            if (d_min) {
+                const float vmin = -wave_max(-o.vmin);
+                if (lane == 0 && vmin < INFINITY) atomicMin(d_min + cur.u, enc_max(vmin));
+            }
         }
         __syncthreads();   // the power rows have been consumed: the region takes the next tile's samples
         if (tn < t_end) {
@@ -362,6 +381,28 @@ __global__ void mel_normalize_kernel(float* __restrict__ out, int t_stride, cons
     const float floor_v = dec_max(d_max[u]) - 8.0f;
     float* row = out + ((int64_t)u * MEL_NMELS + m) * t_stride;
     for (int i = threadIdx.x; i < t; i += blockDim.x) row[i] = (fmaxf(row[i], floor_v) + 4.0f) / 4.0f;
+}
+
+// The clamp of rows that were stored scaled: values below (max - 8 + 4) / 4 are raised to it (AudioPreprocessing.swift:269-276).
+// One workgroup per (utterance, group of 16 mel rows); it leaves at once when the utterance's minimum is not below the floor.
+__global__ void mel_clamp_kernel(float* __restrict__ out, int t_stride, const int* __restrict__ frames_out,
+                                 const unsigned* __restrict__ d_max, const unsigned* __restrict__ d_min, int vec_ok) {
+    const int u = blockIdx.y, grp = blockIdx.x;
+    const unsigned mn = d_min[u];
+    const float floor_v = dec_max(d_max[u]) - 8.0f;
+    if (mn == 0xffffffffu || dec_max(mn) >= floor_v) return;
+    const float floor_s = (floor_v + 4.0f) * 0.25f;
+    const int t = frames_out[u], q = vec_ok ? t >> 2 : 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    for (int m = 16 * grp + wave; m < 16 * grp + 16; m += waves) {
+        float* row = out + ((int64_t)u * MEL_NMELS + m) * t_stride;
+        for (int j = lane; j < q; j += 64) {
+            const float4 v = ((const float4*)row)[j];
+            if (fminf(fminf(v.x, v.y), fminf(v.z, v.w)) < floor_s)
+                ((float4*)row)[j] = make_float4(fmaxf(v.x, floor_s), fmaxf(v.y, floor_s), fmaxf(v.z, floor_s), fmaxf(v.w, floor_s));
+        }
+        for (int j = 4 * q + lane; j < t; j += 64) row[j] = fmaxf(row[j], floor_s);
+    }
 }
 
 // AudioPreprocessing.swift:347-365: index in double, fraction and blend in float, no contraction.
@@ -468,7 +509,8 @@ void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, d
 }
 
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
-                const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work) {
+                const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work,
+                unsigned* d_min) {
     if (n_tiles <= 0) return;
     static PerDeviceOnce once;
     once.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES)); });
@@ -477,7 +519,15 @@ void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, co
     // two workgroups fit per CU (79 KB of LDS each); each loops over its share of the tiles
     hipLaunchKernelGGL(mel_kernel, dim3(std::min(n_tiles, 2 * cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,
                        d_tile_utt, d_tile_f0, n_tiles, t.twid, t.fb_packed, out, t_stride, d_max,
-                       (t_stride % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0);   // 16-byte stores need aligned rows
+                       (t_stride % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0,   // 16-byte stores need aligned rows
+                       d_min);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_mel_clamp(float* out, int B, int t_stride, const int* d_frames_out, const unsigned* d_max, const unsigned* d_min, hipStream_t s) {
+    if (B <= 0) return;
+    hipLaunchKernelGGL(mel_clamp_kernel, dim3(MEL_NMELS / 16, B), dim3(256), 0, s, out, t_stride, d_frames_out, d_max, d_min,
+                       (t_stride % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -508,13 +558,14 @@ struct NoAllocScratch {
     int64_t off[NOALLOC_MAX_UTT];
     int64_t len[NOALLOC_MAX_UTT];
     unsigned dmax[NOALLOC_MAX_UTT];
+    unsigned dmin[NOALLOC_MAX_UTT];
     int frames[NOALLOC_MAX_UTT];
     int tile_utt[NOALLOC_MAX_TILES];
     int tile_f0[NOALLOC_MAX_TILES];
 };
 static_assert(sizeof(NoAllocScratch) <= 200 * 1024, "scratch is meant to stay modest");
 
-// 195 KB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the device address is looked up
+// 196 KB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the device address is looked up
 // once per device and every use below goes through that pointer.
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
 
@@ -540,6 +591,7 @@ __global__ __launch_bounds__(256) void mel_noalloc_setup_kernel(OffsetsArg offs,
         sc->off[u] = offs.v[u];
         sc->len[u] = n;
         sc->dmax[u] = 0u;
+        sc->dmin[u] = 0xffffffffu;
         int t = (int)(n / MEL_HOP);                      // frames returned: min(n / 160, 3000)
         sc->frames[u] = t > MEL_MAX_FRAMES ? MEL_MAX_FRAMES : t;
     }
@@ -608,8 +660,8 @@ void mel_noalloc_run(const MelTables& t, const float* audio_dev, const int64_t* 
     if (!capturing && g_scratch_used[dev]) HIP_CHECK(hipStreamWaitEvent(s, g_scratch_free[dev], 0));   // the previous user has finished
     hipLaunchKernelGGL(mel_noalloc_setup_kernel, dim3(1), dim3(256), 0, s, offs, n_utt, sc);
     HIP_CHECK(hipGetLastError());
-    launch_mel(t, audio_dev, sc->off, sc->len, sc->tile_utt, sc->tile_f0, (int)tiles, mel_out_dev, t_stride, sc->dmax, s, bytes);
-    launch_mel_normalize(mel_out_dev, n_utt, t_stride, sc->frames, sc->dmax, s);
+    launch_mel(t, audio_dev, sc->off, sc->len, sc->tile_utt, sc->tile_f0, (int)tiles, mel_out_dev, t_stride, sc->dmax, s, bytes, sc->dmin);
+    launch_mel_clamp(mel_out_dev, n_utt, t_stride, sc->frames, sc->dmax, sc->dmin, s);
     if (!capturing) {
         HIP_CHECK(hipEventRecord(g_scratch_free[dev], s));
         g_scratch_used[dev] = true;

@@ -64,8 +64,9 @@ struct MelRun {
 
 // src_off / src_len: position of every utterance in `audio` (input sample rate).
 // dst: optional device buffer [b][128][t_stride] that receives the raw log-mel instead of workspace memory.
+// normalize: the rows come back clamped and scaled (the stand-alone stage); otherwise they stay raw for conv1.
 MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>& src_off, const std::vector<int64_t>& src_len,
-               int sample_rate, int t_stride, float* dst = nullptr) {
+               int sample_rate, int t_stride, float* dst = nullptr, bool normalize = false) {
     const int b = (int)src_off.size();
     MelRun r;
     r.n16.resize(b);
@@ -119,8 +120,16 @@ MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>
     r.dmax = c.get<unsigned>(b);
     HIP_CHECK(hipMemsetAsync(r.dmax, 0, (size_t)b * 4, c.s));
     r.d_frames = c.up(r.frames);
+    const char* env_two = getenv("Q3ASR_MEL_TWO_PASS");   // 1: raw rows, then a full clamp-and-scale pass (what the scaled store is measured against)
+    unsigned* d_min = nullptr;
+    if (normalize && !(env_two && atoi(env_two) != 0)) {
+        d_min = c.get<unsigned>(b);
+        HIP_CHECK(hipMemsetAsync(d_min, 0xff, (size_t)b * 4, c.s));
+    }
     launch_mel(c.m->mel, d16, c.up(off16), c.up(r.n16), c.up(tile_utt), c.up(tile_f0), (int)tile_utt.size(), r.raw, r.t_stride,
-               r.dmax, c.s, mel_bytes);
+               r.dmax, c.s, mel_bytes, d_min);
+    if (normalize && d_min) launch_mel_clamp(r.raw, b, r.t_stride, r.d_frames, r.dmax, d_min, c.s);
+    else if (normalize) launch_mel_normalize(r.raw, b, r.t_stride, r.d_frames, r.dmax, c.s);
     return r;
 }
 
@@ -311,8 +320,7 @@ void model_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n
     }
     Q3_REQUIRE(t_stride > 0, "mel: t_stride must be positive");
     const bool direct = out_space == Q3ASR_DEVICE;   // a device caller's buffer is written by the kernels themselves
-    MelRun r = run_mel(c, audio, audio_space, off, len, sample_rate, t_stride, direct ? mel_out : nullptr);
-    launch_mel_normalize(r.raw, n_utt, r.t_stride, r.d_frames, r.dmax, c.s);
+    MelRun r = run_mel(c, audio, audio_space, off, len, sample_rate, t_stride, direct ? mel_out : nullptr, true);
     if (!direct) HIP_CHECK(hipMemcpyAsync(mel_out, r.raw, (size_t)n_utt * MEL_NMELS * r.t_stride * 4, hipMemcpyDeviceToHost, c.s));
     HIP_CHECK(hipStreamSynchronize(c.s));
     for (int u = 0; u < n_utt; ++u) n_frames[u] = r.frames[u];

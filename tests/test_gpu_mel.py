@@ -60,7 +60,7 @@ def test_mel_ragged_batch_and_edges(tiny_model):
         assert g.shape[1] == min(len(a) // 160, 3000)
 
 
-def test_mel_full_batch_1024_clips(tiny_model):
+def test_mel_full_batch_1024_clips(tiny_model, monkeypatch):
     """The mel-only configuration at its full size, 1024 clips x 30 s in one call (1.97 GB in, 1.57 GB out).  The
     restatement cannot cover it in seconds, so three clips are checked against it and the rest through properties:
     a clip's features do not depend on its slot or on its neighbours (64 distinct clips repeated 16 times must give
@@ -80,6 +80,12 @@ def test_mel_full_batch_1024_clips(tiny_model):
         _check(got[i], base[i], 16000, m)
     alone = m.feature_extractor.process(base[5], 16000)
     assert np.array_equal(alone, got[5])
+    # The rows are stored scaled and only clamped afterwards where an utterance needs it; raw rows followed by a full
+    # clamp-and-scale pass must give the same bits everywhere.
+    monkeypatch.setenv("Q3ASR_MEL_TWO_PASS", "1")
+    two = m.feature_extractor.process_batch(clips, 16000)
+    for i in range(1024):
+        assert np.array_equal(two[i], got[i]), i
 
 
 def test_mel_test_wav_24k_resample(tiny_model):
@@ -128,3 +134,31 @@ def test_mel_device_buffers_match_host_path(tiny_model):
     for i, w in enumerate(want):
         assert frames[i] == w.shape[1]
         assert np.array_equal(got[i, :, :frames[i]], w)
+
+
+def test_mel_one_launch_clamp_path_with_silent_stretches(tiny_model, monkeypatch):
+    """600 short utterances (0.2 - 2 s), most with a stretch of digital silence (ten decades under the peak: the max - 8
+    clamp of AudioPreprocessing.swift:269-276 is active there), a few without: rows stored scaled and clamped only where
+    an utterance needs it, against raw rows followed by a full clamp-and-scale pass, bit for bit, and five utterances
+    against the restatement."""
+    m = tiny_model[0]
+    rng = np.random.default_rng(5)
+    clips = []
+    for i in range(600):
+        n = int(rng.integers(3200, 32000))
+        a = synth.synth_audio(n, 7000 + i, "noise" if i % 5 == 4 else "speechlike")
+        if i % 4 != 3:
+            z0 = int(rng.integers(0, n // 2))
+            a[z0:z0 + n // 3] = 0.0
+        clips.append(a)
+    assert m.feature_extractor.process_batch(clips[:1], 16000)[0].shape[0] == 128
+    got = m.feature_extractor.process_batch(clips, 16000)
+    monkeypatch.setenv("Q3ASR_MEL_TWO_PASS", "1")
+    two = m.feature_extractor.process_batch(clips, 16000)
+    clamped = 0
+    for i in range(600):
+        assert np.array_equal(got[i], two[i]), i
+        clamped += int((got[i] == got[i].min()).sum() > 128)       # a clamp floor shows as many equal minima
+    assert clamped >= 300
+    for i in (0, 3, 4, 299, 599):
+        _check(got[i], clips[i], 16000, m)
