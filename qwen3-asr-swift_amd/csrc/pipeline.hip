@@ -832,8 +832,10 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         bool chain = was_split;   // attention and the other kernels are on different streams
         // The halves' attention launches on one stream or on two (both confined to the attention's CUs): on two, a
         // launch starts filling CUs while the other half's previous launch drains, instead of ~11 us after its end.
+        // (Q3ASR_ATT_STREAMS=1: one attention stream for both halves.  A second stream for the second half's projections
+        // was measured as well and changes nothing: 12 379 / 12 194 ms of decode with it, 12 370 without.)
         const char* env_as = getenv("Q3ASR_ATT_STREAMS");
-        const int att_streams = was_split && env_as && atoi(env_as) == 2 ? 2 : 1;
+        const int att_streams = was_split && !(env_as && atoi(env_as) == 1) ? 2 : 1;
         if (was_split) ensure_split_streams(m, att_cus, att_streams == 2);
         // The reference computes nothing for a clip once it has stopped (:571-574).  Here a stopped utterance is skipped by
         // the attention kernel at once (its done flag) and leaves the step's rows at the next poll: the step kernel
@@ -1001,10 +1003,19 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             }
             if (chain) HIP_CHECK(hipEventRecord(ev_pre[h][l], x.s));
         };
+        // Profiling with two attention streams: a launch whose duration is sampled runs alone on the attention's CUs (it
+        // starts after the other half's latest launch has ended, and that half's next launch starts after it), so that
+        // the sample says what the kernel reaches by itself; the unsampled launches overlap as they do without a profile.
+        hipEvent_t last_attn_ev[2] = {nullptr, nullptr}, alone_ev = nullptr;
+        int alone_half = -1;
         auto attn = [&](int h, int l, int it) {
             Half& x = hv[h];
             const DecLayerW& L = m->dec[l];
             if (chain) HIP_CHECK(hipStreamWaitEvent(x.sa, ev_pre[h][l], 0));
+            if (alone_ev && alone_half != h) {
+                HIP_CHECK(hipStreamWaitEvent(x.sa, alone_ev, 0));
+                alone_ev = nullptr;
+            }
             // two attention streams: a step's first launch of the second half starts behind the first half's, which sets
             // the alternation the later layers keep by themselves (each half's next launch waits for its own projections)
             if (chain && att_streams == 2 && h == 1 && l == 0 && hv[0].rows > 0) HIP_CHECK(hipStreamWaitEvent(x.sa, ev_attn[0][0], 0));
@@ -1012,6 +1023,11 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 const bool timed = prof_next_timed("decode_attn_kernel", x.sa);
                 attn_launched[h * per_half + it] += 1;
                 attn_timed[h * per_half + it] += timed ? 1 : 0;
+                if (timed && chain && att_streams == 2) {
+                    if (last_attn_ev[h ^ 1]) HIP_CHECK(hipStreamWaitEvent(x.sa, last_attn_ev[h ^ 1], 0));
+                    alone_half = h;
+                    alone_ev = ev_attn[h][l];
+                }
                 // a timed launch's start event would otherwise be stamped while the stream still waits for the q/k/v rows
                 if (timed && chain) launch_noop(x.sa);
             }
@@ -1025,7 +1041,10 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                                        cfg.rms_eps, m->rope_cos, m->rope_sin, half, cfg.rope_interleaved, m->rope_max_pos};
             }
             launch_decode_attn(dp, hd, x.sa, 0.0);
-            if (chain) HIP_CHECK(hipEventRecord(ev_attn[h][l], x.sa));
+            if (chain) {
+                HIP_CHECK(hipEventRecord(ev_attn[h][l], x.sa));
+                last_attn_ev[h] = ev_attn[h][l];
+            }
         };
         // post: o (+= residual), post norm + gate/up + SwiGLU, down (+= residual)
         auto post = [&](int h, int l) {
