@@ -501,7 +501,12 @@ def main():
                        "decode_attention_cus": 0 if args.workload == "mel" else model.decode_attention_cus(min(n_local, args.batch))},
             "roofline": {"bound": bound, "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
                          "frac": round(ach / peak, 4), "peak_measured_copy": copy_gbs, "peak_measured_read": read_gbs, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 5),
-                         "work_per_launch": per_launch_work, "share_of_device_time": round(top["ms_est"] / sum(p["ms_est"] for p in prof), 3)},
+                         "work_per_launch": per_launch_work, "share_of_device_time": round(top["ms_est"] / sum(p["ms_est"] for p in prof), 3),
+                         # the two halves' attention launches run on two streams and overlap by a fifth of their time; a launch
+                         # whose duration is sampled is made to run alone, so avg_launch_ms is the kernel's own time (what
+                         # rocprofv3 reports per launch when both halves share one stream, Q3ASR_ATT_STREAMS=1)
+                         "sampling": "every %d-th launch, timed with HIP events on its launch stream; a sampled decode-attention launch runs "
+                                     "without the other half's launch beside it" % args.profile_stride},
             "kernels": [{"name": p["name"], "launches_per_step": p["launches"] / args.steps, "ms_per_step": round(p["ms_est"] / args.steps, 2),
                          "rate": round(p["work_timed"] / max(p["ms_timed"], 1e-9) / 1e9, 2)} for p in prof[:16]],
         }

@@ -29,6 +29,19 @@ def main():
         b = int(g)
         hist[b] = hist.get(b, 0) + 1
     print("gap histogram (us: count):", dict(sorted(hist.items())[:25]))
+    # busy share of the kernel's CUs: launches of the two halves may overlap (two streams), so the intervals are merged
+    merged, span0, span1 = 0, att[0][0], max(e for _, e, _, _ in att)
+    cur_s, cur_e = att[0][0], att[0][1]
+    for s, e, _, _ in att[1:]:
+        if s <= cur_e:
+            cur_e = max(cur_e, e)
+        else:
+            merged += cur_e - cur_s
+            cur_s, cur_e = s, e
+    merged += cur_e - cur_s
+    overlap = sum(e - s for s, e, _, _ in att) - merged
+    print(f"from the first launch's start to the last one's end: {(span1 - span0) / 1e6:.2f} ms, some launch of *{sub}* running for "
+          f"{merged / 1e6:.2f} ms = {100.0 * merged / (span1 - span0):.1f} % of it; two launches at once for {overlap / 1e6:.2f} ms")
 
 
 if __name__ == "__main__":
