@@ -25,6 +25,8 @@ void launch_layernorm(const float* x, const float* w, const float* b, bf16_t* ou
 
 // RMSNorm over fp32 rows -> bf16.  rowidx (optional) gathers input rows.  When nslab > 0 the row
 // is first updated in place with the split-K partial sums: x[row] += sum_s slab[s][row].
+// dst[i] = row rowidx[i] of src (bf16 rows of `cols` values, a multiple of 8; source row stride ld)
+void launch_gather_rows_bf16(const bf16_t* src, int64_t ld, const int* rowidx, bf16_t* dst, int rows, int cols, hipStream_t s);
 void launch_rmsnorm(float* x, const float* w, bf16_t* out, int rows, int d, float eps, const int* rowidx, const float* slab,
                     int nslab, int64_t slab_stride, hipStream_t s);
 

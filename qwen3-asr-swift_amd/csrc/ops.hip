@@ -539,6 +539,23 @@ void launch_rmsnorm(float* x, const float* w, bf16_t* out, int rows, int d, floa
     HIP_CHECK(hipGetLastError());
 }
 
+namespace {
+// dst[i][0 .. cols) = src[rowidx[i]][0 .. cols), 16-byte pieces (cols a multiple of 8)
+__global__ void gather_rows_bf16_kernel(const bf16_t* __restrict__ src, int64_t ld, const int* __restrict__ rowidx,
+                                        bf16_t* __restrict__ dst, int cols) {
+    const uint4* s = (const uint4*)(src + (int64_t)rowidx[blockIdx.x] * ld);
+    uint4* d = (uint4*)(dst + (int64_t)blockIdx.x * cols);
+    for (int c = threadIdx.x; c < cols / 8; c += blockDim.x) d[c] = s[c];
+}
+}  // namespace
+
+void launch_gather_rows_bf16(const bf16_t* src, int64_t ld, const int* rowidx, bf16_t* dst, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return;
+    Q3_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "gather: rows must be whole 16-byte pieces");
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(rows), dim3(128), 0, s, src, ld, rowidx, dst, cols);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_rope(const RopeParams& p, hipStream_t s) {
     if (p.rows <= 0) return;
     Q3_REQUIRE(p.half % 2 == 0 && p.half <= 64, "rope: rotary half-dim must be even and <= 64");

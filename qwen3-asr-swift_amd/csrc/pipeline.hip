@@ -777,6 +777,22 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         const AttnTile* d_tiles = c.up(tiles);
         double prefill_attn_flops = 0;  // causal: half of the dense 4 S^2 D per head
         for (auto& sq : seqs) prefill_attn_flops += 2.0 * sq.len * sq.len * hd * nh;
+        // The prefill's only output besides the cache is the last position's hidden state (Qwen3ASR.swift:386-388 takes
+        // logits[-1]).  Every layer needs all rows for its successor, except the last one: its K / V rows go to the cache
+        // for the decode steps, but only the last row of every prompt goes on through attention, o, and the MLP -- one
+        // 64-query tile and one row per utterance instead of S rows.  Each kept value is computed as before (the GEMM
+        // tile never changes a sum), so the tokens are the same bits.  Q3ASR_PREFILL_FULL_LAST=1 computes every row.
+        const char* env_full = getenv("Q3ASR_PREFILL_FULL_LAST");
+        const bool short_last = !(env_full && atoi(env_full) != 0);
+        std::vector<AttnTile> last_tiles;
+        double last_attn_flops = 0;
+        for (int i = 0; i < b; ++i) {
+            const int q0 = (utt_rows[i] - 1) / 64 * 64;
+            last_tiles.push_back({i, q0});
+            last_attn_flops += 4.0 * (utt_rows[i] - q0) * (q0 + 0.5 * (utt_rows[i] - q0)) * hd * nh;
+        }
+        const AttnTile* d_last_tiles = short_last ? c.up(last_tiles) : nullptr;
+        bf16_t* att_last = short_last ? c.get<bf16_t>((size_t)b * nh * hd) : nullptr;
         for (int l = 0; l < cfg.layers; ++l) {
             const DecLayerW& L = m->dec[l];
             launch_rmsnorm(hid, L.in_norm, xn, R, H, cfg.rms_eps, nullptr, nullptr, 0, 0, c.s);
@@ -789,6 +805,29 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                           cfg.rope_interleaved, m->rope_max_pos, d_row_utt, d_row_pos, st_len, kc + l * layer_stride, vc + l * layer_stride,
                           utt_stride, head_stride};
             launch_rope(rp, c.s);
+            if (short_last && l + 1 == cfg.layers) {
+                FlashParams fp{qkv, QKV, kc + l * layer_stride, vc + l * layer_stride, hd, head_stride, att, (int64_t)nh * hd, d_seqs,
+                               d_last_tiles, b, nh, nh / nkv, scale, 1};
+                launch_flash_attn(fp, hd, c.s, last_attn_flops);
+                launch_gather_rows_bf16(att, (int64_t)nh * hd, d_last, att_last, b, nh * hd, c.s);
+                {
+                    GemmParams p = gp(c, att_last, (int64_t)nh * hd, L.o, b);
+                    p.out = hid; p.ldo = H; p.rowmap = d_last;
+                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
+                }
+                launch_rmsnorm(hid, L.post_norm, xn, b, H, cfg.rms_eps, d_last, nullptr, 0, 0, c.s);   // compact rows
+                {
+                    GemmParams p = gp(c, xn, H, L.gate_up, b);
+                    p.out = act; p.ldo = cfg.inter;
+                    launch_gemm(p, A_PLAIN, OUT_SWIGLU, wf, -1, c.s);
+                }
+                {
+                    GemmParams p = gp(c, act, cfg.inter, L.down, b);
+                    p.out = hid; p.ldo = H; p.rowmap = d_last;
+                    launch_gemm(p, A_PLAIN, OUT_F32_ACC, wf, -1, c.s);
+                }
+                break;
+            }
             FlashParams fp{qkv, QKV, kc + l * layer_stride, vc + l * layer_stride, hd, head_stride, att, (int64_t)nh * hd, d_seqs, d_tiles,
                            (int)tiles.size(), nh, nh / nkv, scale, 1};
             launch_flash_attn(fp, hd, c.s, prefill_attn_flops);

@@ -372,3 +372,33 @@ def test_greedy_free_running_matches_oracle_prefix(tiny_model):
     upto = int(below[0]) if below.size else n
     parity.note("free-running greedy prefix", f"{upto} of {n} steps before the first margin below the gate")
     assert got[:upto] == toks[:upto]
+
+
+@pytest.mark.parametrize("preset", ["tiny", "1.7b-2layers"])
+def test_last_prefill_layer_for_the_last_row_only(preset, monkeypatch):
+    """The prefill's last layer runs attention, o and the MLP for the last prompt row of every utterance only (nothing
+    else of that layer is ever read: Qwen3ASR.swift:386-388 takes the last position's logits; its K / V rows are cached
+    as before).  Computing every row (Q3ASR_PREFILL_FULL_LAST=1) must give the same bits: first-step logits, and the
+    tokens of a free-running decode over the cache the prefill left."""
+    if preset == "tiny":
+        cfg = make_config("tiny")
+        lens = (16000, 52345, 480000, 30001, 99999)
+    else:
+        cfg = make_config("1.7b", enc_layers=2, layers=2)
+        lens = (20000, 64000, 33333)
+    ck = synth.make_checkpoint(cfg, seed=17)
+    m = Qwen3ASRModel.from_checkpoint(cfg, ck)
+    try:
+        audios = [synth.synth_audio(n, 310 + i) for i, n in enumerate(lens)]
+        short = m.transcribe_batch(audios, 16000, max_tokens=10, stop_rules=False, tap_steps=2)
+        short_free = m.transcribe_batch(audios, 16000, max_tokens=10, stop_rules=False)
+        prefix = m.transcribe_batch(audios[:2], 16000, max_tokens=4, lang_ids=[[4128, 6364], None], stop_rules=False, tap_steps=1)
+        monkeypatch.setenv("Q3ASR_PREFILL_FULL_LAST", "1")
+        full = m.transcribe_batch(audios, 16000, max_tokens=10, stop_rules=False, tap_steps=2)
+        full_free = m.transcribe_batch(audios, 16000, max_tokens=10, stop_rules=False)
+        prefix_full = m.transcribe_batch(audios[:2], 16000, max_tokens=4, lang_ids=[[4128, 6364], None], stop_rules=False, tap_steps=1)
+        assert np.array_equal(short.taps["logits"], full.taps["logits"])
+        assert short.tokens == full.tokens and short_free.tokens == full_free.tokens
+        assert np.array_equal(prefix.taps["logits"], prefix_full.taps["logits"]) and prefix.tokens == prefix_full.tokens
+    finally:
+        m.close()
