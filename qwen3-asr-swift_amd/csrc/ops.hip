@@ -109,43 +109,46 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
                                                       bf16_t* __restrict__ out, int rows, int d, float eps,
                                                       const int* __restrict__ rowidx, const float* __restrict__ slab,
                                                       int nslab, int64_t slab_stride) {
-    // one workgroup per row: the decode step has few rows and up to 8 slabs each, so the row is
-    // spread over 256 threads to keep enough loads in flight
-    __shared__ float part[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const int64_t src = rowidx ? rowidx[row] : row;
-    const int d4 = d >> 2;
-    float4* x4 = (float4*)(x + src * d);
-    float4 v[2];
-    float sq = 0.f;
+    // A row is spread over the 256 threads of a workgroup (the decode step has few rows and up to 8 slabs each: enough
+    // loads in flight); the workgroups walk the rows with the grid's stride, so that a prefill's 800 000 rows are not
+    // 800 000 workgroup launches.  A row's arithmetic does not depend on which workgroup takes it.
+    __shared__ float part[2][4];
+    const int tid = threadIdx.x, d4 = d >> 2;
+    int flip = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x, flip ^= 1) {
+        const int64_t src = rowidx ? rowidx[row] : row;
+        float4* x4 = (float4*)(x + src * d);
+        float4 v[2];
+        float sq = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = tid + 256 * j;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < d4) {
-            v[j] = x4[c];
-            if (nslab > 0) {
-                for (int s = 0; s < nslab; ++s) {
-                    const float4 t = ((const float4*)(slab + s * slab_stride + src * d))[c];
-                    v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
+        for (int j = 0; j < 2; ++j) {
+            const int c = tid + 256 * j;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < d4) {
+                v[j] = x4[c];
+                if (nslab > 0) {
+                    for (int s = 0; s < nslab; ++s) {
+                        const float4 t = ((const float4*)(slab + s * slab_stride + src * d))[c];
+                        v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
+                    }
+                    x4[c] = v[j];
                 }
-                x4[c] = v[j];
             }
+            sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
         }
-        sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-    }
-    sq = wave_sum(sq);
-    if ((tid & 63) == 0) part[tid >> 6] = sq;
-    __syncthreads();
-    const float rstd = 1.0f / sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)d + eps);
-    bf16_t* o = out + (int64_t)row * d;
+        sq = wave_sum(sq);
+        if ((tid & 63) == 0) part[flip][tid >> 6] = sq;
+        __syncthreads();   // (the other half of `part` is free again once every wave has passed this barrier)
+        const float rstd = 1.0f / sqrtf((part[flip][0] + part[flip][1] + part[flip][2] + part[flip][3]) / (float)d + eps);
+        bf16_t* o = out + (int64_t)row * d;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = tid + 256 * j;
-        if (c < d4) {
-            const float4 ww = ((const float4*)w)[c];
-            *(uint2*)(o + 4 * c) = make_uint2(pack_bf16x2(v[j].x * rstd * ww.x, v[j].y * rstd * ww.y),
-                                              pack_bf16x2(v[j].z * rstd * ww.z, v[j].w * rstd * ww.w));
+        for (int j = 0; j < 2; ++j) {
+            const int c = tid + 256 * j;
+            if (c < d4) {
+                const float4 ww = ((const float4*)w)[c];
+                *(uint2*)(o + 4 * c) = make_uint2(pack_bf16x2(v[j].x * rstd * ww.x, v[j].y * rstd * ww.y),
+                                                  pack_bf16x2(v[j].z * rstd * ww.z, v[j].w * rstd * ww.w));
+            }
         }
     }
 }
@@ -201,8 +204,9 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
 __global__ __launch_bounds__(256) void rope_rows_kernel(RopeParams p) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int slots = p.heads + 2 * p.kv_heads, groups = slots >> 2;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gw >= (int64_t)p.rows * groups) return;
+    // the waves walk the (row, group of four heads) items with the grid's stride: a prefill has millions of them
+    const int64_t total = (int64_t)p.rows * groups;
+    for (int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gw < total; gw += (int64_t)gridDim.x * 4) {
     const int row = (int)(gw / groups), slot = (int)(gw % groups) * 4 + (lane >> 4);
     const int u = p.row_utt ? p.row_utt[row] : row;
     const int pos = p.row_pos ? p.row_pos[row] : p.cur_len[u];
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(RopeParams p) {
                       (int64_t)pos * 128 + 4 * l;
         *(uint2*)dst = ra;
         *(uint2*)(dst + 64) = rb;
-        return;
+        continue;
     }
     const bool is_q = slot < p.heads;
     float a[4] = {__uint_as_float(ra.x << 16), __uint_as_float(ra.x & 0xffff0000u), __uint_as_float(ra.y << 16),
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(RopeParams p) {
                              (int64_t)pos * 128 + 4 * l;
     *(uint2*)dst = oa;
     *(uint2*)(dst + 64) = ob;
+    }
 }
 
 // ------------------------------------------------------------------ embedding gather / splice
@@ -534,7 +539,8 @@ void launch_rmsnorm(float* x, const float* w, bf16_t* out, int rows, int d, floa
                     int nslab, int64_t slab_stride, hipStream_t s) {
     if (rows <= 0) return;
     Q3_REQUIRE(d % 4 == 0 && d <= 2048, "rmsnorm: width must be a multiple of 4 and <= 2048");
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, s, x, w, out, rows, d, eps, rowidx, slab, nslab,
+    // at most 16 workgroups per CU (two rounds of the eight that fit): beyond that each walks several rows
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(std::min(rows, 16 * device_cus())), dim3(256), 0, s, x, w, out, rows, d, eps, rowidx, slab, nslab,
                        slab_stride);
     HIP_CHECK(hipGetLastError());
 }
@@ -562,7 +568,7 @@ void launch_rope(const RopeParams& p, hipStream_t s) {
     const int slots = p.heads + 2 * p.kv_heads;
     if (!p.slab && slots % 4 == 0 && p.ld % 4 == 0 && p.q_ld % 4 == 0 && (p.interleaved || p.half == 64)) {
         const int64_t waves4 = (int64_t)p.rows * (slots / 4);
-        hipLaunchKernelGGL(rope_rows_kernel, dim3(cdiv(waves4, 4)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(rope_rows_kernel, dim3(std::min<int64_t>(cdiv(waves4, 4), 16 * device_cus())), dim3(256), 0, s, p);
         HIP_CHECK(hipGetLastError());
         return;
     }
