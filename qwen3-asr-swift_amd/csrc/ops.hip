@@ -204,9 +204,10 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeParams p) {
 __global__ __launch_bounds__(256) void rope_rows_kernel(RopeParams p) {
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int slots = p.heads + 2 * p.kv_heads, groups = slots >> 2;
-    // the waves walk the (row, group of four heads) items with the grid's stride: a prefill has millions of them
-    const int64_t total = (int64_t)p.rows * groups;
-    for (int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gw < total; gw += (int64_t)gridDim.x * 4) {
+    // (one wave per item: walking the items with the grid's stride, as the RMSNorm kernel does with its rows, was measured
+    // and is slower here, prefill +2 %: an item is two dependent loads deep, and fresh workgroups keep more of them in flight)
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (int64_t)p.rows * groups) return;
     const int row = (int)(gw / groups), slot = (int)(gw % groups) * 4 + (lane >> 4);
     const int u = p.row_utt ? p.row_utt[row] : row;
     const int pos = p.row_pos ? p.row_pos[row] : p.cur_len[u];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(RopeParams p) {
                       (int64_t)pos * 128 + 4 * l;
         *(uint2*)dst = ra;
         *(uint2*)(dst + 64) = rb;
-        continue;
+        return;
     }
     const bool is_q = slot < p.heads;
     float a[4] = {__uint_as_float(ra.x << 16), __uint_as_float(ra.x & 0xffff0000u), __uint_as_float(ra.y << 16),
@@ -268,7 +269,6 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(RopeParams p) {
                              (int64_t)pos * 128 + 4 * l;
     *(uint2*)dst = oa;
     *(uint2*)(dst + 64) = ob;
-    }
 }
 
 // ------------------------------------------------------------------ embedding gather / splice
@@ -568,7 +568,7 @@ void launch_rope(const RopeParams& p, hipStream_t s) {
     const int slots = p.heads + 2 * p.kv_heads;
     if (!p.slab && slots % 4 == 0 && p.ld % 4 == 0 && p.q_ld % 4 == 0 && (p.interleaved || p.half == 64)) {
         const int64_t waves4 = (int64_t)p.rows * (slots / 4);
-        hipLaunchKernelGGL(rope_rows_kernel, dim3(std::min<int64_t>(cdiv(waves4, 4), 16 * device_cus())), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(rope_rows_kernel, dim3(cdiv(waves4, 4)), dim3(256), 0, s, p);
         HIP_CHECK(hipGetLastError());
         return;
     }

@@ -1,6 +1,6 @@
 # Round 3, run h: RMSNorm walking rows with the grid's stride: model / retire tests, then the 96-token bench line.
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r3_h
+O=$R/gpurun_out/r3_i
 mkdir -p $O
 cd $R
 timeout -k 10 800 python -u -m pytest tests/test_gpu_model.py tests/test_gpu_retire.py tests/test_gpu_golden.py -m gpu -x -q --timeout 300 --timeout-method thread > $O/tests.log 2>&1
