@@ -1342,6 +1342,9 @@ void model_transcribe(q3asr_model* m, const q3asr_request* req, q3asr_result* re
     }
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return frames[a] > frames[b]; });
+    // (Full groups and a rest: cutting a request a little above max_batch into even groups instead was measured on 2840
+    // pieces of ragged recordings, 2 x 1420 against 2048 + 792, and is slower, 3524 x against 3579 x real time: a group
+    // decodes the faster per utterance the larger it is.)
     const int mb = std::max(1, cfg.max_batch);
     for (int g0 = 0; g0 < n; g0 += mb) {
         std::vector<int> idx(order.begin() + g0, order.begin() + std::min(n, g0 + mb));
