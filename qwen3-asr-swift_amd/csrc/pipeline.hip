@@ -1015,10 +1015,24 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
         // The step of one half is issued in four kinds of pieces.  Every per-step quantity is read from device arrays,
         // so the launches of all steps between two polls are identical; `it` only feeds the profiler and the logits tap.
         // pre: [token embedding,] input norm and q/k/v projection of layer l
+        // Diagnostic (Q3ASR_SPLIT_SERIAL=1): the two CU-confined streams take turns instead of running side by side (every
+        // attention launch waits for all projection work issued so far and the other way round), which shows what each
+        // kernel reaches on its share of the compute units with the other share idle.
+        const char* env_serial = getenv("Q3ASR_SPLIT_SERIAL");
+        const bool serial = was_split && env_serial && atoi(env_serial) != 0;
+        hipEvent_t ev_ser_mm = nullptr, ev_ser_att = nullptr;
+        bool ser_mm_set = false, ser_att_set = false;
+        if (serial) {
+            HIP_CHECK(hipEventCreateWithFlags(&ev_ser_mm, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&ev_ser_att, hipEventDisableTiming));
+        }
+        auto ser_before_mm = [&](hipStream_t s) { if (serial && chain && ser_att_set) HIP_CHECK(hipStreamWaitEvent(s, ev_ser_att, 0)); };
+        auto ser_after_mm = [&](hipStream_t s) { if (serial && chain) { HIP_CHECK(hipEventRecord(ev_ser_mm, s)); ser_mm_set = true; } };
         auto pre = [&](int h, int l) {
             Half& x = hv[h];
             const DecLayerW& L = m->dec[l];
             const int* map = st_map[x.cur] + x.r0;
+            ser_before_mm(x.s);
             if (l == 0)
                 launch_embed_tokens(st_next, map, x.rows, H, qemb ? nullptr : (const bf16_t*)m->embed.w,
                                     qemb ? (const uint32_t*)m->embed.w : nullptr, m->embed.scales, m->embed.biases, cfg.group_size, x.hid, x.s);
@@ -1041,6 +1055,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
                 launch_rope(rp, x.s);
             }
             if (chain) HIP_CHECK(hipEventRecord(ev_pre[h][l], x.s));
+            ser_after_mm(x.s);
         };
         // Profiling with two attention streams: a launch whose duration is sampled runs alone on the attention's CUs (it
         // starts after the other half's latest launch has ended, and that half's next launch starts after it), so that
@@ -1051,6 +1066,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             Half& x = hv[h];
             const DecLayerW& L = m->dec[l];
             if (chain) HIP_CHECK(hipStreamWaitEvent(x.sa, ev_pre[h][l], 0));
+            if (serial && chain && ser_mm_set) HIP_CHECK(hipStreamWaitEvent(x.sa, ev_ser_mm, 0));
             if (alone_ev && alone_half != h) {
                 HIP_CHECK(hipStreamWaitEvent(x.sa, alone_ev, 0));
                 alone_ev = nullptr;
@@ -1083,6 +1099,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             if (chain) {
                 HIP_CHECK(hipEventRecord(ev_attn[h][l], x.sa));
                 last_attn_ev[h] = ev_attn[h][l];
+                if (serial) { HIP_CHECK(hipEventRecord(ev_ser_att, x.sa)); ser_att_set = true; }
             }
         };
         // post: o (+= residual), post norm + gate/up + SwiGLU, down (+= residual)
@@ -1090,6 +1107,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             Half& x = hv[h];
             const DecLayerW& L = m->dec[l];
             if (chain) HIP_CHECK(hipStreamWaitEvent(x.s, ev_attn[h][l], 0));
+            ser_before_mm(x.s);
             if (x.gemv) {
                 GemvParams g;
                 g.M = x.rows; g.eps = cfg.rms_eps; g.qgroup = cfg.group_size;
@@ -1107,6 +1125,7 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             const int ns_gu = proj(x, x.xn, H, L.gate_up, 2, OUT_SWIGLU, x.act, cfg.inter);
             if (ns_gu) launch_swiglu_reduce(x.slab, ns_gu, (int64_t)x.rows * 2 * cfg.inter, x.rows, 2 * cfg.inter, x.act, x.s);
             pend_down[h] = proj(x, x.act, cfg.inter, L.down, 3, OUT_F32_ACC, x.hid, H);
+            ser_after_mm(x.s);
         };
         // tail: final norm, LM head, bookkeeping
         auto tail = [&](int h, int it) {
@@ -1271,6 +1290,11 @@ void transcribe_group(Ctx& c, const q3asr_request* req, q3asr_result* res, const
             }
         }
         cur_cus = 0;
+        if (serial) {
+            HIP_CHECK(hipStreamSynchronize(c.s));
+            (void)hipEventDestroy(ev_ser_mm);
+            (void)hipEventDestroy(ev_ser_att);
+        }
         if (prof_active(c.s)) {
             std::vector<long long> keys(2 * per_half);
             HIP_CHECK(hipMemcpyAsync(keys.data(), st_keys, keys.size() * sizeof(long long), hipMemcpyDeviceToHost, c.s));
