@@ -64,10 +64,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Maximum over the 64 lanes of a wave, returned in every lane.  All 64 lanes must be active.  Lane exchanges inside a row
+// of 16 are register moves with a DPP modifier (a shuffle through the LDS crossbar costs a memory round trip per step);
+// the four row results are then read out of lanes 0 / 16 / 32 / 48.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_move<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_move<0x124>(v));   // row_ror:4
+    v = fmaxf(v, dpp_move<0x128>(v));   // row_ror:8
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 #endif
 

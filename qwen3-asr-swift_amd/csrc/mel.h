@@ -28,13 +28,17 @@ void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, d
 // audio: concatenated 16 kHz samples; d_off[u] / d_len[u]: start and length of utterance u.
 // d_tile_utt / d_tile_f0: one entry per MEL_TILE_FRAMES-frame tile.  out: [B][128][t_stride] raw log10 mel.
 // d_max: [B] order-preserving encodings of the per-utterance maximum (zeroed by the caller).
-// d_min: null (raw rows), or [B] words set to 0xffffffff by the caller: the rows are then stored scaled, (y + 4) / 4, and
-// d_min receives the encodings of the per-utterance minimum of the returned values; launch_mel_clamp finishes the job.
+// d_tile_min: null (raw rows), or [n_tiles][16] floats: the rows are then stored scaled, (y + 4) / 4, and every tile's
+// sixteen cells of 16 frames x 16 mel rows ([2][8]) receive the minimum of their returned values before scaling;
+// launch_mel_clamp finishes the job.
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
                 const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work = 0,
-                unsigned* d_min = nullptr);
-// The max-8 clamp on rows stored scaled; costs next to nothing for utterances without a value under their floor.
-void launch_mel_clamp(float* out, int B, int t_stride, const int* d_frames_out, const unsigned* d_max, const unsigned* d_min, hipStream_t s);
+                float* d_tile_min = nullptr);
+// Expands d_tile0 ([B + 1] running tile counts: utterance u owns tiles [tile0[u], tile0[u + 1])) into the kernel's tile list.
+void launch_mel_tiles(const int* d_tile0, int B, int* d_tile_utt, int* d_tile_f0, hipStream_t s);
+// The max-8 clamp on rows stored scaled: only cells whose minimum lies under their utterance's floor are read again.
+void launch_mel_clamp(float* out, int t_stride, int n_tiles, const int* d_tile_utt, const int* d_tile_f0, const int* d_frames_out,
+                      const unsigned* d_max, const float* d_tile_min, hipStream_t s);
 // In-place clamp / scale of rows [0, frames_out[u]) with the per-utterance maximum.
 void launch_mel_normalize(float* out, int B, int t_stride, const int* d_frames_out, const unsigned* d_max, hipStream_t s);
 

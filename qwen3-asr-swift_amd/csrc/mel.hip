@@ -123,29 +123,46 @@ struct MelTileOut {
     int n_store;         // how many of the lane's four frames are returned (0..4)
     int n_max;           // how many of them count for the running maximum
     bool vec;            // 16-byte stores allowed
-    bool scaled;         // store (y + 4) / 4 instead of y and keep the minimum of what is stored
-    float vmax, vmin;
+    float vmax;
+    float* cell_min;     // SCALED: the eight per-column-tile minima of this wave's 16 frames
 };
 
-// One column tile: CT = tile, OFF = position of its first weight fragment in the wave's register-resident list.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// One column tile's products: CT = tile, OFF = position of its first weight fragment in the wave's register-resident list.
+// All of the tile's LDS reads are issued before the first product, and a wave's column tiles are independent chains
+// that the scheduler interleaves.
 template <int CT, int OFF>
-__device__ __forceinline__ void mel_col_tile(const float* pw, const float (&bf)[SET_STEPS], int n, MelTileOut& o) {
-    typedef __attribute__((ext_vector_type(4))) float f32x4;
+__device__ __forceinline__ f32x4 mel_col_product(const float* pw, const float (&bf)[SET_STEPS]) {
+    float a[ct_steps(CT)];
+#pragma unroll
+    for (int s = 0; s < ct_steps(CT); ++s) a[s] = pw[ct_lo(CT) + 4 * s];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < ct_steps(CT); ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[ct_lo(CT) + 4 * s], bf[OFF + s], acc, 0, 0, 0);
+    for (int s = 0; s < ct_steps(CT); ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bf[OFF + s], acc, 0, 0, 0);
+    return acc;
+}
+
+// log10, running extrema and the store of one column tile.  SCALED: store (y + 4) / 4 instead of y and keep the
+// minimum of what is stored.
+template <int CT, bool SCALED>
+__device__ __forceinline__ void mel_col_store(f32x4 acc, int n, int lane, MelTileOut& o) {
     // log10 of the clamped filter output (AudioPreprocessing.swift:232-255).  The hardware log2 is accurate to 1 ulp
     // and the argument is never denormal, so the plain product is within 2e-6 of the correctly rounded value.
-    float y[4];
+    float y[4], vmin = INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma clang fp contract(off)   // log10 is rounded before the scale touches it, exactly as when it is stored raw and scaled by its consumer
         y[r] = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
-        if (r < o.n_max) o.vmax = fmaxf(o.vmax, y[r]);
-        if (o.scaled) {
-            if (r < o.n_store) o.vmin = fminf(o.vmin, y[r]);
+        o.vmax = fmaxf(o.vmax, r < o.n_max ? y[r] : -INFINITY);
+        if (SCALED) {
+            vmin = fminf(vmin, r < o.n_store ? y[r] : INFINITY);
             y[r] = (y[r] + 4.0f) * 0.25f;    // AudioPreprocessing.swift:286-288
         }
+    }
+    if (SCALED) {
+        vmin = -wave_max(-vmin);
+        if (lane == 0) o.cell_min[CT] = vmin;
     }
     float* dst = o.out + (int64_t)(16 * CT + n) * o.t_stride;
     if (o.vec && o.n_store == 4) {
@@ -208,14 +225,64 @@ __device__ __forceinline__ cpx tw25(cpx a, int b, int c) {
     return cmul(a, (cpx){C[b - 1][c - 1], S[b - 1][c - 1]});
 }
 
+// Phase 1 of a tile, one item = (frame f, residue n2): the item's eight windowed sample pairs, then the butterfly.
+__device__ __forceinline__ void bfly_load(const float* xs, const float* tab, int u, cpx (&z)[8]) {
+    const int f = u / 25, n2 = u - 25 * f;
+    const cpx* xf = (const cpx*)(xs + f * MEL_HOP) + n2;
+    const cpx* hw = (const cpx*)(tab + TAB_HANN) + n2;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) z[n1] = xf[25 * n1] * hw[25 * n1];
+}
+__device__ __forceinline__ void bfly_store(cpx* zc, const float* tab, int u, const cpx (&z)[8]) {
+    const int f = u / 25, n2 = u - 25 * f;
+    const cpx* w = (const cpx*)(tab + TAB_TW) + n2 + 25;    // [k1][n2] (cos, -sin): consecutive lanes read consecutive pairs
+    const cpx a0 = z[0] + z[4], a1 = z[0] - z[4], a2 = z[2] + z[6], a3 = z[2] - z[6];
+    const cpx b0 = z[1] + z[5], b1 = z[1] - z[5], b2 = z[3] + z[7], b3 = z[3] - z[7];
+    const cpx c0 = a0 + a2, c2 = a0 - a2, c1 = add_mi(a1, a3), c3 = add_pi(a1, a3);
+    const cpx e0 = b0 + b2, e2 = b0 - b2, e1 = add_mi(b1, b3), e3 = add_pi(b1, b3);
+    const cpx R = splat(0.70710678118654752440f);
+    const cpx w1 = R * add_mi(e1, e1);    // e1 * (1 - i) / sqrt 2
+    const cpx w3 = R * add_pi(e3, e3);    // -e3 * (-1 - i) / sqrt 2
+    cpx y[8];
+    y[0] = c0 + e0; y[4] = c0 - e0;
+    y[1] = c1 + w1; y[5] = c1 - w1;
+    y[2] = add_mi(c2, e2); y[6] = add_pi(c2, e2);
+    y[3] = c3 - w3; y[7] = c3 + w3;
+    cpx* yo = zc + f * ZS + n2;
+    yo[0] = y[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) yo[25 * k1] = cmul(y[k1], w[25 * (k1 - 1)]);
+}
+
+// Phase 3 of a tile, one item = (frame f, bin pair k / 200 - k).
+__device__ __forceinline__ void untangle_load(const cpx* zc, const float* tab, int u, cpx& A, cpx& B, cpx& W) {
+    const int f = u / 101, k = u - 101 * f;
+    A = zc[f * ZS + k];
+    B = zc[f * ZS + (k == 0 ? 0 : 200 - k)];
+    W = ((const cpx*)(tab + TAB_UW))[k];
+}
+__device__ __forceinline__ void untangle_store(float* xs, int u, cpx A, cpx B, cpx W) {
+    const int f = u / 101, k = u - 101 * f;
+    cpx E2, O2;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(E2) : "v"(A), "v"(B));                               // (ar + br, ai - bi)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(O2) : "v"(A), "v"(B));  // (ai + bi, br - ar)
+    const cpx T = cmul(O2, W);
+    const cpx X = E2 + T, Y = E2 - T;
+    const cpx X2 = X * X, Y2 = Y * Y;
+    float* pw = xs + f * POW_STRIDE;
+    pw[k] = 0.25f * (X2.x + X2.y);
+    if (k > 0 && k < 100) pw[200 - k] = 0.25f * (Y2.x + Y2.y);
+}
+
 // Persistent workgroups, each looping over tiles of 32 frames.
+template <bool SCALED>
 __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __restrict__ audio, const int64_t* __restrict__ d_off,
                                                              const int64_t* __restrict__ d_len, const int* __restrict__ tile_utt,
                                                              const int* __restrict__ tile_f0, int n_tiles,
                                                              const float* __restrict__ tables,
                                                              const float* __restrict__ fb_frags, float* __restrict__ out,
                                                              int t_stride, unsigned* __restrict__ d_max, int vec_ok,
-                                                             unsigned* __restrict__ d_min) {
+                                                             float* __restrict__ tile_min) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* xs = sm;                           // samples of the tile; from phase 3 on the power rows [32][201]
     cpx* zc = (cpx*)(sm + XS_N);              // transform values [32][200], (re, im) pairs
@@ -253,30 +320,12 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
         if (tn < t_end) fetch_samples(tile_info(audio, d_off, d_len, tile_utt, tile_f0, tn), sv, tid);
 
         // ---- phase 1: window, radix-8 butterflies over n1 (z index m = 25 n1 + n2), twiddles W200^(n2 k1) ----
-        for (int u = tid; u < TF * 25; u += MEL_THREADS) {
-            const int f = u / 25, n2 = u - 25 * f;
-            const cpx* xf = (const cpx*)(xs + f * MEL_HOP) + n2;
-            const cpx* hw = (const cpx*)(tab + TAB_HANN) + n2;
+        {
             cpx z[8];
-#pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) z[n1] = xf[25 * n1] * hw[25 * n1];
-            const cpx a0 = z[0] + z[4], a1 = z[0] - z[4], a2 = z[2] + z[6], a3 = z[2] - z[6];
-            const cpx b0 = z[1] + z[5], b1 = z[1] - z[5], b2 = z[3] + z[7], b3 = z[3] - z[7];
-            const cpx c0 = a0 + a2, c2 = a0 - a2, c1 = add_mi(a1, a3), c3 = add_pi(a1, a3);
-            const cpx e0 = b0 + b2, e2 = b0 - b2, e1 = add_mi(b1, b3), e3 = add_pi(b1, b3);
-            const cpx R = splat(0.70710678118654752440f);
-            const cpx w1 = R * add_mi(e1, e1);    // e1 * (1 - i) / sqrt 2
-            const cpx w3 = R * add_pi(e3, e3);    // -e3 * (-1 - i) / sqrt 2
-            cpx y[8];
-            y[0] = c0 + e0; y[4] = c0 - e0;
-            y[1] = c1 + w1; y[5] = c1 - w1;
-            y[2] = add_mi(c2, e2); y[6] = add_pi(c2, e2);
-            y[3] = c3 - w3; y[7] = c3 + w3;
-            const cpx* tw = (const cpx*)(tab + TAB_TW) + n2;    // [k1][n2] (cos, -sin): consecutive lanes read consecutive pairs
-            cpx* yo = zc + f * ZS + n2;
-            yo[0] = y[0];
-#pragma unroll
-            for (int k1 = 1; k1 < 8; ++k1) yo[25 * k1] = cmul(y[k1], tw[25 * k1]);
+            for (int u = tid; u < TF * 25; u += MEL_THREADS) {
+                bfly_load(xs, tab, u, z);
+                bfly_store(zc, tab, u, z);
+            }
         }
         __syncthreads();
 
@@ -314,19 +363,19 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
         __syncthreads();
 
         // ---- phase 3: real spectrum from A = Z[k] and B = Z[200 - k]: with E2 = A + conj B and O2 = -i (A - conj B),
-        //      X[k] = (E2 + w O2) / 2 and conj X[200 - k] = (E2 - w O2) / 2, w = exp(-i pi k / 200).  Bin 200 feeds no filter. ----
-        for (int u = tid; u < TF * 101; u += MEL_THREADS) {
-            const int f = u / 101, k = u - 101 * f;
-            const cpx A = zc[f * ZS + k], B = zc[f * ZS + (k == 0 ? 0 : 200 - k)];
-            cpx E2, O2;
-            asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(E2) : "v"(A), "v"(B));                               // (ar + br, ai - bi)
-            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(O2) : "v"(A), "v"(B));  // (ai + bi, br - ar)
-            const cpx T = cmul(O2, ((const cpx*)(tab + TAB_UW))[k]);
-            const cpx X = E2 + T, Y = E2 - T;
-            const cpx X2 = X * X, Y2 = Y * Y;
-            float* pw = xs + f * POW_STRIDE;
-            pw[k] = 0.25f * (X2.x + X2.y);
-            if (k > 0 && k < 100) pw[200 - k] = 0.25f * (Y2.x + Y2.y);
+        //      X[k] = (E2 + w O2) / 2 and conj X[200 - k] = (E2 - w O2) / 2, w = exp(-i pi k / 200).  Bin 200 feeds no filter.
+        //      3232 items: twelve rounds of 256 in groups of four with all reads first, then the 160 left over. ----
+        for (int it = 0; it < 12; it += 4) {
+            cpx A[4], B[4], W[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) untangle_load(zc, tab, tid + (it + j) * MEL_THREADS, A[j], B[j], W[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) untangle_store(xs, tid + (it + j) * MEL_THREADS, A[j], B[j], W[j]);
+        }
+        if (tid + 12 * MEL_THREADS < TF * 101) {
+            cpx A, B, W;
+            untangle_load(zc, tab, tid + 12 * MEL_THREADS, A, B, W);
+            untangle_store(xs, tid + 12 * MEL_THREADS, A, B, W);
         }
         __syncthreads();
 
@@ -344,27 +393,30 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
             // running maximum over every frame the reference computes, the dropped last one included (:269-270)
             o.n_max = min(max(frames_total - frame0, 0), 4);
             o.vec = vec_ok;
-            o.scaled = d_min != nullptr;
             o.vmax = -INFINITY;
-            o.vmin = INFINITY;
+            o.cell_min = SCALED ? tile_min + ((int64_t)t * 2 + rt) * 8 : nullptr;
             const float* pw = xs + (16 * rt + n) * POW_STRIDE + g;   // A operand: row = frame, k = bin
             if (wave < 2) {
-                mel_col_tile<7, 0>(pw, bf, n, o);
-                mel_col_tile<5, ct_steps(7)>(pw, bf, n, o);
-                mel_col_tile<0, ct_steps(7) + ct_steps(5)>(pw, bf, n, o);
+                const f32x4 a7 = mel_col_product<7, 0>(pw, bf);
+                const f32x4 a5 = mel_col_product<5, ct_steps(7)>(pw, bf);
+                const f32x4 a0 = mel_col_product<0, ct_steps(7) + ct_steps(5)>(pw, bf);
+                mel_col_store<7, SCALED>(a7, n, lane, o);
+                mel_col_store<5, SCALED>(a5, n, lane, o);
+                mel_col_store<0, SCALED>(a0, n, lane, o);
             } else {
-                mel_col_tile<6, 0>(pw, bf, n, o);
-                mel_col_tile<4, ct_steps(6)>(pw, bf, n, o);
-                mel_col_tile<3, ct_steps(6) + ct_steps(4)>(pw, bf, n, o);
-                mel_col_tile<2, ct_steps(6) + ct_steps(4) + ct_steps(3)>(pw, bf, n, o);
-                mel_col_tile<1, ct_steps(6) + ct_steps(4) + ct_steps(3) + ct_steps(2)>(pw, bf, n, o);
+                const f32x4 a6 = mel_col_product<6, 0>(pw, bf);
+                const f32x4 a4 = mel_col_product<4, ct_steps(6)>(pw, bf);
+                const f32x4 a3 = mel_col_product<3, ct_steps(6) + ct_steps(4)>(pw, bf);
+                const f32x4 a2 = mel_col_product<2, ct_steps(6) + ct_steps(4) + ct_steps(3)>(pw, bf);
+                const f32x4 a1 = mel_col_product<1, ct_steps(6) + ct_steps(4) + ct_steps(3) + ct_steps(2)>(pw, bf);
+                mel_col_store<6, SCALED>(a6, n, lane, o);
+                mel_col_store<4, SCALED>(a4, n, lane, o);
+                mel_col_store<3, SCALED>(a3, n, lane, o);
+                mel_col_store<2, SCALED>(a2, n, lane, o);
+                mel_col_store<1, SCALED>(a1, n, lane, o);
             }
             const float vmax = wave_max(o.vmax);
             if (lane == 0 && vmax > -INFINITY) atomicMax(d_max + cur.u, enc_max(vmax));
-            if (d_min) {
-                const float vmin = -wave_max(-o.vmin);
-                if (lane == 0 && vmin < INFINITY) atomicMin(d_min + cur.u, enc_max(vmin));
-            }
         }
         __syncthreads();   // the power rows have been consumed: the region takes the next tile's samples
         if (tn < t_end) {
@@ -384,24 +436,46 @@ __global__ void mel_normalize_kernel(float* __restrict__ out, int t_stride, cons
 }
 
 // The clamp of rows that were stored scaled: values below (max - 8 + 4) / 4 are raised to it (AudioPreprocessing.swift:269-276).
-// One workgroup per (utterance, group of 16 mel rows); it leaves at once when the utterance's minimum is not below the floor.
-__global__ void mel_clamp_kernel(float* __restrict__ out, int t_stride, const int* __restrict__ frames_out,
-                                 const unsigned* __restrict__ d_max, const unsigned* __restrict__ d_min, int vec_ok) {
-    const int u = blockIdx.y, grp = blockIdx.x;
-    const unsigned mn = d_min[u];
+// tile_min holds, per tile, the minimum of each cell of 16 frames x 16 mel rows ([2][8] per tile).  One wave per tile:
+// it leaves at once when no cell's minimum is below the utterance's floor, and otherwise visits the cells that are,
+// one 16-byte piece (four frames of one row) per lane.
+__global__ __launch_bounds__(256) void mel_clamp_kernel(float* __restrict__ out, int t_stride, int n_tiles,
+                                                        const int* __restrict__ tile_utt, const int* __restrict__ tile_f0,
+                                                        const int* __restrict__ frames_out, const unsigned* __restrict__ d_max,
+                                                        const float* __restrict__ tile_min, int vec_ok) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int u = tile_utt[t], f0 = tile_f0[t];
     const float floor_v = dec_max(d_max[u]) - 8.0f;
-    if (mn == 0xffffffffu || dec_max(mn) >= floor_v) return;
+    const float mn = lane < 16 ? tile_min[(int64_t)t * 16 + lane] : INFINITY;
+    unsigned long long flagged = __ballot(mn < floor_v);
+    if (!flagged) return;
     const float floor_s = (floor_v + 4.0f) * 0.25f;
-    const int t = frames_out[u], q = vec_ok ? t >> 2 : 0;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
-    for (int m = 16 * grp + wave; m < 16 * grp + 16; m += waves) {
-        float* row = out + ((int64_t)u * MEL_NMELS + m) * t_stride;
-        for (int j = lane; j < q; j += 64) {
-            const float4 v = ((const float4*)row)[j];
+    const int frames = frames_out[u], row = lane >> 2, q = lane & 3;
+    while (flagged) {
+        const int cell = __builtin_ctzll(flagged);   // cell = 8 rt + ct
+        flagged &= flagged - 1;
+        const int fr = f0 + 16 * (cell >> 3) + 4 * q;
+        float* p = out + ((int64_t)u * MEL_NMELS + 16 * (cell & 7) + row) * t_stride + fr;
+        const int nv = min(max(frames - fr, 0), 4);
+        if (vec_ok && nv == 4) {
+            const float4 v = *(const float4*)p;
             if (fminf(fminf(v.x, v.y), fminf(v.z, v.w)) < floor_s)
-                ((float4*)row)[j] = make_float4(fmaxf(v.x, floor_s), fmaxf(v.y, floor_s), fmaxf(v.z, floor_s), fmaxf(v.w, floor_s));
+                *(float4*)p = make_float4(fmaxf(v.x, floor_s), fmaxf(v.y, floor_s), fmaxf(v.z, floor_s), fmaxf(v.w, floor_s));
+        } else {
+            for (int r = 0; r < nv; ++r)
+                if (p[r] < floor_s) p[r] = floor_s;
         }
-        for (int j = 4 * q + lane; j < t; j += 64) row[j] = fmaxf(row[j], floor_s);
+    }
+}
+
+// Tile list of a batch: utterance u owns tiles [tile0[u], tile0[u + 1]).
+__global__ void mel_tiles_kernel(const int* __restrict__ tile0, int* __restrict__ tile_utt, int* __restrict__ tile_f0) {
+    const int u = blockIdx.x, first = tile0[u], last = tile0[u + 1];
+    for (int i = first + threadIdx.x; i < last; i += blockDim.x) {
+        tile_utt[i] = u;
+        tile_f0[i] = (i - first) * MEL_TILE_FRAMES;
     }
 }
 
@@ -508,26 +582,38 @@ void launch_resample(const float* in, int64_t n_in, float* out, int64_t n_out, d
     HIP_CHECK(hipGetLastError());
 }
 
+static void mel_kernel_attributes() {
+    HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES));
+    HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES));
+}
+
 void launch_mel(const MelTables& t, const float* audio, const int64_t* d_off, const int64_t* d_len, const int* d_tile_utt,
                 const int* d_tile_f0, int n_tiles, float* out, int t_stride, unsigned* d_max, hipStream_t s, double work,
-                unsigned* d_min) {
+                float* d_tile_min) {
     if (n_tiles <= 0) return;
     static PerDeviceOnce once;
-    once.run([&] { HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES)); });
+    once.run([&] { mel_kernel_attributes(); });
     const int cus = device_cus();
     ProfScope ps("mel_kernel", work, s);
     // two workgroups fit per CU (79 KB of LDS each); each loops over its share of the tiles
-    hipLaunchKernelGGL(mel_kernel, dim3(std::min(n_tiles, 2 * cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,
+    hipLaunchKernelGGL(d_tile_min ? mel_kernel<true> : mel_kernel<false>, dim3(std::min(n_tiles, 2 * cus)), dim3(MEL_THREADS), MEL_LDS_BYTES, s, audio, d_off, d_len,
                        d_tile_utt, d_tile_f0, n_tiles, t.twid, t.fb_packed, out, t_stride, d_max,
                        (t_stride % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0,   // 16-byte stores need aligned rows
-                       d_min);
+                       d_tile_min);
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_mel_clamp(float* out, int B, int t_stride, const int* d_frames_out, const unsigned* d_max, const unsigned* d_min, hipStream_t s) {
+void launch_mel_tiles(const int* d_tile0, int B, int* d_tile_utt, int* d_tile_f0, hipStream_t s) {
     if (B <= 0) return;
-    hipLaunchKernelGGL(mel_clamp_kernel, dim3(MEL_NMELS / 16, B), dim3(256), 0, s, out, t_stride, d_frames_out, d_max, d_min,
-                       (t_stride % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0);
+    hipLaunchKernelGGL(mel_tiles_kernel, dim3(B), dim3(64), 0, s, d_tile0, d_tile_utt, d_tile_f0);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_mel_clamp(float* out, int t_stride, int n_tiles, const int* d_tile_utt, const int* d_tile_f0, const int* d_frames_out,
+                      const unsigned* d_max, const float* d_tile_min, hipStream_t s) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(mel_clamp_kernel, dim3(cdiv(n_tiles, 4)), dim3(256), 0, s, out, t_stride, n_tiles, d_tile_utt, d_tile_f0,
+                       d_frames_out, d_max, d_tile_min, (t_stride % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -558,14 +644,14 @@ struct NoAllocScratch {
     int64_t off[NOALLOC_MAX_UTT];
     int64_t len[NOALLOC_MAX_UTT];
     unsigned dmax[NOALLOC_MAX_UTT];
-    unsigned dmin[NOALLOC_MAX_UTT];
     int frames[NOALLOC_MAX_UTT];
     int tile_utt[NOALLOC_MAX_TILES];
     int tile_f0[NOALLOC_MAX_TILES];
+    float tile_min[NOALLOC_MAX_TILES * 16];   // per tile: minima of its [2][8] cells of 16 frames x 16 mel rows
 };
-static_assert(sizeof(NoAllocScratch) <= 200 * 1024, "scratch is meant to stay modest");
+static_assert(sizeof(NoAllocScratch) <= 1800 * 1024, "scratch is meant to stay modest");
 
-// 196 KB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the device address is looked up
+// 1.7 MB per GPU.  In host code this name is only a handle for hipGetSymbolAddress: the device address is looked up
 // once per device and every use below goes through that pointer.
 static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
 
@@ -591,7 +677,6 @@ __global__ __launch_bounds__(256) void mel_noalloc_setup_kernel(OffsetsArg offs,
         sc->off[u] = offs.v[u];
         sc->len[u] = n;
         sc->dmax[u] = 0u;
-        sc->dmin[u] = 0xffffffffu;
         int t = (int)(n / MEL_HOP);                      // frames returned: min(n / 160, 3000)
         sc->frames[u] = t > MEL_MAX_FRAMES ? MEL_MAX_FRAMES : t;
     }
@@ -622,7 +707,7 @@ void mel_noalloc_init() {
         HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         g_scratch_ptr[dev] = (NoAllocScratch*)p;
         HIP_CHECK(hipEventCreateWithFlags(&g_scratch_free[dev], hipEventDisableTiming));
-        HIP_CHECK(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES));
+        mel_kernel_attributes();
     });
 }
 
@@ -660,8 +745,8 @@ void mel_noalloc_run(const MelTables& t, const float* audio_dev, const int64_t* 
     if (!capturing && g_scratch_used[dev]) HIP_CHECK(hipStreamWaitEvent(s, g_scratch_free[dev], 0));   // the previous user has finished
     hipLaunchKernelGGL(mel_noalloc_setup_kernel, dim3(1), dim3(256), 0, s, offs, n_utt, sc);
     HIP_CHECK(hipGetLastError());
-    launch_mel(t, audio_dev, sc->off, sc->len, sc->tile_utt, sc->tile_f0, (int)tiles, mel_out_dev, t_stride, sc->dmax, s, bytes, sc->dmin);
-    launch_mel_clamp(mel_out_dev, n_utt, t_stride, sc->frames, sc->dmax, sc->dmin, s);
+    launch_mel(t, audio_dev, sc->off, sc->len, sc->tile_utt, sc->tile_f0, (int)tiles, mel_out_dev, t_stride, sc->dmax, s, bytes, sc->tile_min);
+    launch_mel_clamp(mel_out_dev, t_stride, (int)tiles, sc->tile_utt, sc->tile_f0, sc->frames, sc->dmax, sc->tile_min, s);
     if (!capturing) {
         HIP_CHECK(hipEventRecord(g_scratch_free[dev], s));
         g_scratch_used[dev] = true;

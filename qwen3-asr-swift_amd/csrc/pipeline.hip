@@ -105,13 +105,16 @@ MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>
         }
         d16 = buf;
     }
-    std::vector<int> tile_utt, tile_f0;
+    std::vector<int> tile0(b + 1, 0);   // the device expands the running counts into the tile list
     int tmax = 1;
     for (int u = 0; u < b; ++u) {
-        const int total = mel_frames_total(r.n16[u]);
-        for (int f0 = 0; f0 < total; f0 += MEL_TILE_FRAMES) { tile_utt.push_back(u); tile_f0.push_back(f0); }
+        tile0[u + 1] = tile0[u] + (mel_frames_total(r.n16[u]) + MEL_TILE_FRAMES - 1) / MEL_TILE_FRAMES;
         tmax = std::max(tmax, r.frames[u]);
     }
+    const int n_tiles = tile0[b];
+    int* d_tile_utt = c.get<int>(std::max(n_tiles, 1));
+    int* d_tile_f0 = c.get<int>(std::max(n_tiles, 1));
+    launch_mel_tiles(c.up(tile0), b, d_tile_utt, d_tile_f0, c.s);
     r.t_stride = t_stride > 0 ? t_stride : ((tmax + 3) & ~3);
     Q3_REQUIRE(r.t_stride >= tmax, "mel: t_stride is smaller than the longest utterance's frame count");
     double mel_bytes = 0;  // algorithmic traffic: samples in + returned frames out
@@ -121,14 +124,10 @@ MelRun run_mel(Ctx& c, const float* audio, int space, const std::vector<int64_t>
     HIP_CHECK(hipMemsetAsync(r.dmax, 0, (size_t)b * 4, c.s));
     r.d_frames = c.up(r.frames);
     const char* env_two = getenv("Q3ASR_MEL_TWO_PASS");   // 1: raw rows, then a full clamp-and-scale pass (what the scaled store is measured against)
-    unsigned* d_min = nullptr;
-    if (normalize && !(env_two && atoi(env_two) != 0)) {
-        d_min = c.get<unsigned>(b);
-        HIP_CHECK(hipMemsetAsync(d_min, 0xff, (size_t)b * 4, c.s));
-    }
-    launch_mel(c.m->mel, d16, c.up(off16), c.up(r.n16), c.up(tile_utt), c.up(tile_f0), (int)tile_utt.size(), r.raw, r.t_stride,
-               r.dmax, c.s, mel_bytes, d_min);
-    if (normalize && d_min) launch_mel_clamp(r.raw, b, r.t_stride, r.d_frames, r.dmax, d_min, c.s);
+    float* d_min = nullptr;   // per tile: minima of its sixteen cells
+    if (normalize && !(env_two && atoi(env_two) != 0)) d_min = c.get<float>((size_t)std::max(n_tiles, 1) * 16);
+    launch_mel(c.m->mel, d16, c.up(off16), c.up(r.n16), d_tile_utt, d_tile_f0, n_tiles, r.raw, r.t_stride, r.dmax, c.s, mel_bytes, d_min);
+    if (normalize && d_min) launch_mel_clamp(r.raw, r.t_stride, n_tiles, d_tile_utt, d_tile_f0, r.d_frames, r.dmax, d_min, c.s);
     else if (normalize) launch_mel_normalize(r.raw, b, r.t_stride, r.d_frames, r.dmax, c.s);
     return r;
 }
