@@ -40,7 +40,8 @@ constexpr int ZS = 200;                                           // complex val
 constexpr int Z_N = TF * ZS;
 // tables (floats): Hann window [400] | W200^(n2 k1) as (cos, -sin) pairs [8][25] | exp(-i pi k / 200) as (cos, -sin) pairs [101]
 constexpr int TAB_HANN = 0, TAB_TW = 400, TAB_UW = 800, TAB_N = 1002;
-constexpr int MEL_LDS_BYTES = (XS_N + 2 * Z_N + TAB_N + 6) * 4;  // 80 960 bytes: two workgroups per CU
+constexpr int TAB_LDS = TAB_N - TAB_UW;                          // only the untangling twiddles are staged in LDS
+constexpr int MEL_LDS_BYTES = (XS_N + 2 * Z_N + TAB_LDS + 6) * 4;  // 77 760 bytes: two workgroups per CU
 static_assert(XS_N >= SAMPLES && XS_N >= TF * POW_STRIDE, "sample image and power rows share one region");
 static_assert(MEL_LDS_BYTES <= 80 * 1024, "two workgroups must fit a CU's 160 KB");
 constexpr int NLOAD = (SAMPLES + MEL_THREADS - 1) / MEL_THREADS;  // 21 samples per thread per tile
@@ -145,7 +146,8 @@ __device__ __forceinline__ f32x4 mel_col_product(const float* pw, const float (&
 
 // log10, running extrema and the store of one column tile.  SCALED: store (y + 4) / 4 instead of y and keep the
 // minimum of what is stored.
-template <int CT, bool SCALED>
+// FULL: all four frames of every lane are returned and 16-byte stores are allowed (a tile inside its utterance).
+template <int CT, bool SCALED, bool FULL>
 __device__ __forceinline__ void mel_col_store(f32x4 acc, int n, int lane, MelTileOut& o) {
     // log10 of the clamped filter output (AudioPreprocessing.swift:232-255).  The hardware log2 is accurate to 1 ulp
     // and the argument is never denormal, so the plain product is within 2e-6 of the correctly rounded value.
@@ -154,9 +156,9 @@ __device__ __forceinline__ void mel_col_store(f32x4 acc, int n, int lane, MelTil
     for (int r = 0; r < 4; ++r) {
 #pragma clang fp contract(off)   // log10 is rounded before the scale touches it, exactly as when it is stored raw and scaled by its consumer
         y[r] = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
-        o.vmax = fmaxf(o.vmax, r < o.n_max ? y[r] : -INFINITY);
+        o.vmax = fmaxf(o.vmax, FULL || r < o.n_max ? y[r] : -INFINITY);
         if (SCALED) {
-            vmin = fminf(vmin, r < o.n_store ? y[r] : INFINITY);
+            vmin = fminf(vmin, FULL || r < o.n_store ? y[r] : INFINITY);
             y[r] = (y[r] + 4.0f) * 0.25f;    // AudioPreprocessing.swift:286-288
         }
     }
@@ -165,12 +167,37 @@ __device__ __forceinline__ void mel_col_store(f32x4 acc, int n, int lane, MelTil
         if (lane == 0) o.cell_min[CT] = vmin;
     }
     float* dst = o.out + (int64_t)(16 * CT + n) * o.t_stride;
-    if (o.vec && o.n_store == 4) {
+    if (FULL || (o.vec && o.n_store == 4)) {
         *(float4*)dst = make_float4(y[0], y[1], y[2], y[3]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (r < o.n_store) dst[r] = y[r];
+    }
+}
+
+// Phase 4 of a tile for one wave: waves 0-1 apply column tiles {7, 5, 0} and waves 2-3 {6, 4, 3, 2, 1} to the 16 frames
+// of row tile wave % 2.
+template <bool SCALED, bool FULL>
+__device__ __forceinline__ void mel_filterbank(const float* pw, const float (&bf)[SET_STEPS], int wave, int n, int lane, MelTileOut& o) {
+    if (wave < 2) {
+        const f32x4 a7 = mel_col_product<7, 0>(pw, bf);
+        const f32x4 a5 = mel_col_product<5, ct_steps(7)>(pw, bf);
+        const f32x4 a0 = mel_col_product<0, ct_steps(7) + ct_steps(5)>(pw, bf);
+        mel_col_store<7, SCALED, FULL>(a7, n, lane, o);
+        mel_col_store<5, SCALED, FULL>(a5, n, lane, o);
+        mel_col_store<0, SCALED, FULL>(a0, n, lane, o);
+    } else {
+        const f32x4 a6 = mel_col_product<6, 0>(pw, bf);
+        const f32x4 a4 = mel_col_product<4, ct_steps(6)>(pw, bf);
+        const f32x4 a3 = mel_col_product<3, ct_steps(6) + ct_steps(4)>(pw, bf);
+        const f32x4 a2 = mel_col_product<2, ct_steps(6) + ct_steps(4) + ct_steps(3)>(pw, bf);
+        const f32x4 a1 = mel_col_product<1, ct_steps(6) + ct_steps(4) + ct_steps(3) + ct_steps(2)>(pw, bf);
+        mel_col_store<6, SCALED, FULL>(a6, n, lane, o);
+        mel_col_store<4, SCALED, FULL>(a4, n, lane, o);
+        mel_col_store<3, SCALED, FULL>(a3, n, lane, o);
+        mel_col_store<2, SCALED, FULL>(a2, n, lane, o);
+        mel_col_store<1, SCALED, FULL>(a1, n, lane, o);
     }
 }
 
@@ -225,17 +252,14 @@ __device__ __forceinline__ cpx tw25(cpx a, int b, int c) {
     return cmul(a, (cpx){C[b - 1][c - 1], S[b - 1][c - 1]});
 }
 
-// Phase 1 of a tile, one item = (frame f, residue n2): the item's eight windowed sample pairs, then the butterfly.
-__device__ __forceinline__ void bfly_load(const float* xs, const float* tab, int u, cpx (&z)[8]) {
-    const int f = u / 25, n2 = u - 25 * f;
+// Phase 1 of a tile, one item = (frame f, residue n2): eight windowed sample pairs, the radix-8 butterfly, the twiddles.
+// A lane keeps its residue for the whole kernel, so its eight window pairs hw and seven twiddles tw live in registers.
+__device__ __forceinline__ void bfly_load(const float* xs, int f, int n2, const cpx (&hw)[8], cpx (&z)[8]) {
     const cpx* xf = (const cpx*)(xs + f * MEL_HOP) + n2;
-    const cpx* hw = (const cpx*)(tab + TAB_HANN) + n2;
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) z[n1] = xf[25 * n1] * hw[25 * n1];
+    for (int n1 = 0; n1 < 8; ++n1) z[n1] = xf[25 * n1] * hw[n1];
 }
-__device__ __forceinline__ void bfly_store(cpx* zc, const float* tab, int u, const cpx (&z)[8]) {
-    const int f = u / 25, n2 = u - 25 * f;
-    const cpx* w = (const cpx*)(tab + TAB_TW) + n2 + 25;    // [k1][n2] (cos, -sin): consecutive lanes read consecutive pairs
+__device__ __forceinline__ void bfly_store(cpx* zc, int f, int n2, const cpx (&tw)[7], const cpx (&z)[8]) {
     const cpx a0 = z[0] + z[4], a1 = z[0] - z[4], a2 = z[2] + z[6], a3 = z[2] - z[6];
     const cpx b0 = z[1] + z[5], b1 = z[1] - z[5], b2 = z[3] + z[7], b3 = z[3] - z[7];
     const cpx c0 = a0 + a2, c2 = a0 - a2, c1 = add_mi(a1, a3), c3 = add_pi(a1, a3);
@@ -251,7 +275,7 @@ __device__ __forceinline__ void bfly_store(cpx* zc, const float* tab, int u, con
     cpx* yo = zc + f * ZS + n2;
     yo[0] = y[0];
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) yo[25 * k1] = cmul(y[k1], w[25 * (k1 - 1)]);
+    for (int k1 = 1; k1 < 8; ++k1) yo[25 * k1] = cmul(y[k1], tw[k1 - 1]);
 }
 
 // Phase 3 of a tile, one item = (frame f, bin pair k / 200 - k).
@@ -259,7 +283,7 @@ __device__ __forceinline__ void untangle_load(const cpx* zc, const float* tab, i
     const int f = u / 101, k = u - 101 * f;
     A = zc[f * ZS + k];
     B = zc[f * ZS + (k == 0 ? 0 : 200 - k)];
-    W = ((const cpx*)(tab + TAB_UW))[k];
+    W = ((const cpx*)tab)[k];
 }
 __device__ __forceinline__ void untangle_store(float* xs, int u, cpx A, cpx B, cpx W) {
     const int f = u / 101, k = u - 101 * f;
@@ -267,11 +291,15 @@ __device__ __forceinline__ void untangle_store(float* xs, int u, cpx A, cpx B, c
     asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(E2) : "v"(A), "v"(B));                               // (ar + br, ai - bi)
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(O2) : "v"(A), "v"(B));  // (ai + bi, br - ar)
     const cpx T = cmul(O2, W);
-    const cpx X = E2 + T, Y = E2 - T;
-    const cpx X2 = X * X, Y2 = Y * Y;
+    // X = E2 + T and Y = E2 - T, held as P = (X.re, Y.re) and Q = (X.im, Y.im): both squared magnitudes come out of
+    // one packed product and one packed fused multiply-add.  The factor 1/4 lives in the filterbank weights.
+    cpx P, Q;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(P) : "v"(E2), "v"(T));   // (er + tr, er - tr)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(Q) : "v"(E2), "v"(T));   // (ei + ti, ei - ti)
+    const cpx PW = __builtin_elementwise_fma(Q, Q, P * P);
     float* pw = xs + f * POW_STRIDE;
-    pw[k] = 0.25f * (X2.x + X2.y);
-    if (k > 0 && k < 100) pw[200 - k] = 0.25f * (Y2.x + Y2.y);
+    pw[k] = PW.x;
+    if (k > 0 && k < 100) pw[200 - k] = PW.y;
 }
 
 // Persistent workgroups, each looping over tiles of 32 frames.
@@ -290,7 +318,15 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int i = tid; i < TAB_N; i += MEL_THREADS) tab[i] = tables[i];
+    for (int i = tid; i < TAB_LDS; i += MEL_THREADS) tab[i] = tables[TAB_UW + i];
+    // phase-1 role of this lane: lanes 0-49 of every wave work, on residue n2 of frame 8 r + p1_fr in round r
+    const bool p1 = lane < 50;
+    const int p1_item = wave * 50 + min(lane, 49), p1_fr = p1_item / 25, n2 = p1_item - 25 * p1_fr;
+    cpx hw[8], tw[7];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) hw[n1] = ((const cpx*)(tables + TAB_HANN))[25 * n1 + n2];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) tw[k1 - 1] = ((const cpx*)(tables + TAB_TW))[25 * k1 + n2];   // [k1][n2] (cos, -sin)
     // this wave's filterbank fragments (B operand of the phase-4 products) stay in registers for the whole kernel
     float bf[SET_STEPS];
 #pragma unroll
@@ -319,12 +355,14 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
         // the next tile's samples travel through registers while this tile is transformed
         if (tn < t_end) fetch_samples(tile_info(audio, d_off, d_len, tile_utt, tile_f0, tn), sv, tid);
 
-        // ---- phase 1: window, radix-8 butterflies over n1 (z index m = 25 n1 + n2), twiddles W200^(n2 k1) ----
-        {
+        // ---- phase 1: window, radix-8 butterflies over n1 (z index m = 25 n1 + n2), twiddles W200^(n2 k1): four rounds
+        //      of 200 items, 50 lanes per wave ----
+        if (p1) {
             cpx z[8];
-            for (int u = tid; u < TF * 25; u += MEL_THREADS) {
-                bfly_load(xs, tab, u, z);
-                bfly_store(zc, tab, u, z);
+#pragma unroll
+            for (int r = 0; r < TF / 8; ++r) {
+                bfly_load(xs, 8 * r + p1_fr, n2, hw, z);
+                bfly_store(zc, 8 * r + p1_fr, n2, tw, z);
             }
         }
         __syncthreads();
@@ -396,25 +434,8 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
             o.vmax = -INFINITY;
             o.cell_min = SCALED ? tile_min + ((int64_t)t * 2 + rt) * 8 : nullptr;
             const float* pw = xs + (16 * rt + n) * POW_STRIDE + g;   // A operand: row = frame, k = bin
-            if (wave < 2) {
-                const f32x4 a7 = mel_col_product<7, 0>(pw, bf);
-                const f32x4 a5 = mel_col_product<5, ct_steps(7)>(pw, bf);
-                const f32x4 a0 = mel_col_product<0, ct_steps(7) + ct_steps(5)>(pw, bf);
-                mel_col_store<7, SCALED>(a7, n, lane, o);
-                mel_col_store<5, SCALED>(a5, n, lane, o);
-                mel_col_store<0, SCALED>(a0, n, lane, o);
-            } else {
-                const f32x4 a6 = mel_col_product<6, 0>(pw, bf);
-                const f32x4 a4 = mel_col_product<4, ct_steps(6)>(pw, bf);
-                const f32x4 a3 = mel_col_product<3, ct_steps(6) + ct_steps(4)>(pw, bf);
-                const f32x4 a2 = mel_col_product<2, ct_steps(6) + ct_steps(4) + ct_steps(3)>(pw, bf);
-                const f32x4 a1 = mel_col_product<1, ct_steps(6) + ct_steps(4) + ct_steps(3) + ct_steps(2)>(pw, bf);
-                mel_col_store<6, SCALED>(a6, n, lane, o);
-                mel_col_store<4, SCALED>(a4, n, lane, o);
-                mel_col_store<3, SCALED>(a3, n, lane, o);
-                mel_col_store<2, SCALED>(a2, n, lane, o);
-                mel_col_store<1, SCALED>(a1, n, lane, o);
-            }
+            if (vec_ok && cur.f0 + TF <= frames_out) mel_filterbank<SCALED, true>(pw, bf, wave, n, lane, o);   // workgroup-uniform
+            else mel_filterbank<SCALED, false>(pw, bf, wave, n, lane, o);
             const float vmax = wave_max(o.vmax);
             if (lane == 0 && vmax > -INFINITY) atomicMax(d_max + cur.u, enc_max(vmax));
         }
@@ -551,7 +572,7 @@ void mel_tables_create(MelTables& t) {
             if (!(b >= FB_LO[m] && b < FB_LO[m] + FB_W[m]))
                 Q3_REQUIRE(fabsf(t.host_fb[(size_t)m * MEL_NBINS + b]) < 1e-9f, "mel: the filterbank has a weight outside the kernel's filter supports");
     // Weight fragments of the banded products: lane (n = lane & 15, kg = lane >> 4) of step s of column tile ct holds
-    // W[bin = ct_lo + 4 s + kg][filter 16 ct + n], exactly zero outside the filter's support (so whatever the kernel
+    // W[bin = ct_lo + 4 s + kg][filter 16 ct + n] / 4 (an exact scaling: the power rows hold four times the power), exactly zero outside the filter's support (so whatever the kernel
     // reads beside a row's bins contributes nothing).
     std::vector<float> frags((size_t)2 * SET_STEPS * 64, 0.f);
     for (int set = 0; set < 2; ++set) {
@@ -563,7 +584,7 @@ void mel_tables_create(MelTables& t) {
                 for (int lane = 0; lane < 64; ++lane) {
                     const int m = 16 * ct + (lane & 15), bin = ct_lo(ct) + 4 * st + (lane >> 4);
                     if (bin >= FB_LO[m] && bin < FB_LO[m] + FB_W[m])
-                        frags[((size_t)set * SET_STEPS + pos) * 64 + lane] = t.host_fb[(size_t)m * MEL_NBINS + bin];
+                        frags[((size_t)set * SET_STEPS + pos) * 64 + lane] = 0.25f * t.host_fb[(size_t)m * MEL_NBINS + bin];   // phase 3 leaves 4 |X|^2
                 }
         }
         Q3_REQUIRE(pos == SET_STEPS, "mel: filter set size mismatch");

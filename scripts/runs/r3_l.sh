@@ -1,4 +1,4 @@
-# Log-mel stage after the restructuring (per-cell minima + wave-per-tile clamp): tests, then the stand-alone stage.
+# Log-mel stage: tests, then the stand-alone stage.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r3_l
@@ -6,11 +6,9 @@ rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 400 python -u -m pytest tests/test_gpu_mel.py tests/test_zz_no_alloc.py tests/test_gpu_golden.py -x -q --timeout 120 --timeout-method thread > $O/tests.txt 2>&1 || { tail -30 $O/tests.txt; exit 1; }
 tail -1 $O/tests.txt
-for a in speechlike gapped noise; do
-timeout -k 10 200 python bench.py --workload mel --batch 1024 --audio $a --steps 20 --warmup 3 > $O/mel_b1024_$a.json 2> $O/mel.err || { tail -5 $O/mel.err; exit 1; }
-done
-Q3ASR_MEL_TWO_PASS=1 timeout -k 10 200 python bench.py --workload mel --batch 1024 --steps 20 --warmup 3 > $O/mel_b1024_two_pass.json 2> $O/mel.err || { tail -5 $O/mel.err; exit 1; }
-timeout -k 10 200 python bench.py --workload mel --batch 2048 --steps 20 --warmup 3 > $O/mel_b2048_speechlike.json 2> $O/mel.err || { tail -5 $O/mel.err; exit 1; }
+for a in speechlike gapped; do for i in 1 2; do
+timeout -k 10 200 python bench.py --workload mel --batch 1024 --audio $a --steps 20 --warmup 3 > $O/mel_b1024_${a}_$i.json 2> $O/mel.err || { tail -5 $O/mel.err; exit 1; }
+done; done
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$O/mel_*.json")):
