@@ -292,11 +292,17 @@ __device__ __forceinline__ void untangle_store(float* xs, int u, cpx A, cpx B, c
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(O2) : "v"(A), "v"(B));  // (ai + bi, br - ar)
     const cpx T = cmul(O2, W);
     // X = E2 + T and Y = E2 - T, held as P = (X.re, Y.re) and Q = (X.im, Y.im): both squared magnitudes come out of
-    // one packed product and one packed fused multiply-add.  The factor 1/4 lives in the filterbank weights.
+    // three packed instructions, each square rounded before the sum (no fused multiply-add: the rounding is part of
+    // the result).  The factor 1/4 lives in the filterbank weights.
     cpx P, Q;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(P) : "v"(E2), "v"(T));   // (er + tr, er - tr)
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(Q) : "v"(E2), "v"(T));   // (ei + ti, ei - ti)
-    const cpx PW = __builtin_elementwise_fma(Q, Q, P * P);
+    cpx PW;
+    {
+#pragma clang fp contract(off)
+        const cpx P2 = P * P, Q2 = Q * Q;
+        PW = P2 + Q2;
+    }
     float* pw = xs + f * POW_STRIDE;
     pw[k] = PW.x;
     if (k > 0 && k < 100) pw[200 - k] = PW.y;
@@ -319,9 +325,10 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (int i = tid; i < TAB_LDS; i += MEL_THREADS) tab[i] = tables[TAB_UW + i];
-    // phase-1 role of this lane: lanes 0-49 of every wave work, on residue n2 of frame 8 r + p1_fr in round r
-    const bool p1 = lane < 50;
-    const int p1_item = wave * 50 + min(lane, 49), p1_fr = p1_item / 25, n2 = p1_item - 25 * p1_fr;
+    // phase-1 role of this thread: threads 0-249 take residue n2 = tid % 25 of frame 10 r + tid / 25 in rounds r = 0..2;
+    // frames 30 and 31 go to lanes 0-49 of one wave (fifty consecutive threads hold every residue twice), a different
+    // wave from tile to tile so that no SIMD always carries the extra round
+    const int n2 = tid % 25, p1_fr = tid / 25;
     cpx hw[8], tw[7];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) hw[n1] = ((const cpx*)(tables + TAB_HANN))[25 * n1 + n2];
@@ -347,6 +354,7 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) xs[tid + i * MEL_THREADS] = sv[i];
     }
+    int tile_count = 0;
     for (; t < t_end; t += t_step) {
         const TileInfo cur = tile_info(audio, d_off, d_len, tile_utt, tile_f0, t);
         const int tn = t + t_step;
@@ -355,15 +363,21 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void mel_kernel(const float* __rest
         // the next tile's samples travel through registers while this tile is transformed
         if (tn < t_end) fetch_samples(tile_info(audio, d_off, d_len, tile_utt, tile_f0, tn), sv, tid);
 
-        // ---- phase 1: window, radix-8 butterflies over n1 (z index m = 25 n1 + n2), twiddles W200^(n2 k1): four rounds
-        //      of 200 items, 50 lanes per wave ----
-        if (p1) {
+        // ---- phase 1: window, radix-8 butterflies over n1 (z index m = 25 n1 + n2), twiddles W200^(n2 k1) ----
+        {
             cpx z[8];
+            if (tid < 250) {
 #pragma unroll
-            for (int r = 0; r < TF / 8; ++r) {
-                bfly_load(xs, 8 * r + p1_fr, n2, hw, z);
-                bfly_store(zc, 8 * r + p1_fr, n2, tw, z);
+                for (int r = 0; r < 3; ++r) {
+                    bfly_load(xs, 10 * r + p1_fr, n2, hw, z);
+                    bfly_store(zc, 10 * r + p1_fr, n2, tw, z);
+                }
             }
+            if (wave == (tile_count & 3) && lane < 50) {
+                bfly_load(xs, 30 + (lane >= 25), n2, hw, z);
+                bfly_store(zc, 30 + (lane >= 25), n2, tw, z);
+            }
+            ++tile_count;
         }
         __syncthreads();
 
