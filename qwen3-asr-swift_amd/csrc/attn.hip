@@ -35,6 +35,23 @@ union Frag {
     uint2 h[2];
 };
 
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: one
+// v_permlane16_swap for the row pairs and one v_permlane32_swap for the wave halves -- two vector-ALU moves, no trip
+// through the LDS crossbar and no address arithmetic.  swap(x, x) returns (rows 0 0 2 2, rows 1 1 3 3) resp.
+// (lower half twice, upper half twice).
+__device__ __forceinline__ float rows_max(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));                                 // lanes l ^ 16
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(h[0]), __uint_as_float(h[1]));                              // lanes l ^ 32
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(h[0]) + __uint_as_float(h[1]);
+}
+
 // G: query heads of one KV head that a workgroup computes against each staged K/V tile (1 or 2)
 template <int D, bool CAUSAL, int G>
 __global__ __launch_bounds__(256, G == 2 ? 3 : 1) void flash_kernel(FlashParams p) {
@@ -135,8 +152,7 @@ __global__ __launch_bounds__(256, G == 2 ? 3 : 1) void flash_kernel(FlashParams 
                     sv[nt * 4 + r] = ok ? s[g][nt][r] * sl2 : -INFINITY;
                     tmax = fmaxf(tmax, sv[nt * 4 + r]);
                 }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = rows_max(tmax);
             const float m_new = fmaxf(m[g], tmax);
             alpha[g] = exp2f(m[g] - m_new);
             float ps = 0.f, pe[8];
@@ -168,8 +184,7 @@ __global__ __launch_bounds__(256, G == 2 ? 3 : 1) void flash_kernel(FlashParams 
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float lt = l[g];
-        lt += __shfl_xor(lt, 16, 64);
-        lt += __shfl_xor(lt, 32, 64);
+        lt = rows_sum(lt);
         if (qi < len) {
             const float inv = 1.0f / lt;
             bf16_t* orow = p.O + (seq.q_row0 + qi) * p.o_ld + (h0 + g) * D + 4 * lg;
@@ -182,19 +197,6 @@ __global__ __launch_bounds__(256, G == 2 ? 3 : 1) void flash_kernel(FlashParams 
 }
 
 #undef FLASH_LOAD
-
-// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane: one LDS-crossbar
-// swizzle for the row pair and one v_permlane32_swap for the wave halves, no address arithmetic.
-__device__ __forceinline__ float rows_max(float x) {
-    x = fmaxf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401f)));   // lanes l ^ 16
-    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(h[0]), __uint_as_float(h[1]));                              // lanes l ^ 32
-}
-__device__ __forceinline__ float rows_sum(float x) {
-    x += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401f));
-    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(h[0]) + __uint_as_float(h[1]);
-}
 
 // WAVES = 4 for large groups (three workgroups share a CU); 8 when there are fewer (utterance, head) items than CUs,
 // so that one item's keys are streamed by twice as many waves.
