@@ -69,7 +69,7 @@ int q3asr_mel(q3asr_model* m, const float* audio, const int64_t* offsets, int n_
 /* q3asr_mel for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
  * that forbid it).  No counterpart in the reference.  Same kernels and the same result as q3asr_mel on device buffers, but
  * no hipMalloc / hipFree / host-to-device copy happens inside: what q3asr_mel takes from the model's workspace (offsets on the
- * device, the tile list, per-utterance maxima and frame counts) lives in a fixed 196 KB device array that every GPU holds
+ * device, the tile list, per-utterance maxima, frame counts and per-cell minima) lives in a fixed 1.7 MB device array that every GPU holds
  * until the process ends.  Limits of that array: 16 kHz input only, at most 256 utterances and 24 064 tiles of 32 frames
  * (256 clips of 30 s) per call, at most 600 s per utterance; anything larger is rejected with an error.  audio_dev and
  * mel_out_dev ([n_utt][128][t_stride] fp32) are device pointers, offsets ([n_utt + 1]) and n_frames ([n_utt]) host

@@ -8,21 +8,28 @@
 // transform per (frame, residue mod 8), itself 5 x 5 in registers), and the real spectrum is untangled from Z[k] and
 // Z[200-k].  About 10 kFLOP per frame instead of 160 kFLOP for the folded direct DFT.
 //
-// Work is cut into tiles of 32 frames of one utterance; persistent workgroups of 256 threads (two per CU, 79 KB of LDS each)
+// Work is cut into tiles of 32 frames of one utterance; persistent workgroups of 256 threads (two per CU, 76 KB of LDS each)
 // loop over the tiles.  Per tile: the 5 360 samples it covers are staged in LDS (fetched into registers during the previous
 // tile's arithmetic); phase 1 windows the samples and runs the 800 radix-8 butterflies; phase 2 the 256 25-point transforms;
 // phase 3 untangles the 101 bin pairs of every frame into power values; phase 4 applies the slaney filterbank with
 // compile-time filter supports, log10, the per-utterance running maximum (wave reduction + one atomic per wave) and stores
-// [mel][frame] rows, 32 consecutive frames per store.  The max-8 clamp needs the utterance-wide maximum.  Inside the
-// transcription pipeline the rows are stored raw and the consumer (conv1) clamps and scales them.  For callers that want
-// the reference's exact output tensor the rows are stored already scaled, (y + 4) / 4, and the kernel also keeps each
-// utterance's minimum: the clamp only changes values more than eight decades under the utterance's peak (digital silence,
-// the near-DC filters of a clean signal), so launch_mel_clamp afterwards leaves at once for every utterance whose minimum
-// is above the floor and rewrites only the 16-byte pieces that hold a value below it elsewhere.  (Minima per group of 16
-// mel rows, so that the clamp could skip most rows of the other utterances too, were measured: the eight extra wave
-// reductions per tile cost the log-mel kernel more, 2.06 -> 2.38 ms per 1024 clips, than the clamp saves.)  x -> (x + 4) / 4 is monotonic in fp32, so
-// clamping the scaled value to the scaled floor gives the bits of scaling the clamped value.  Twiddles are rounded from double; the window multiplies the samples in fp32 as the
-// reference does (:161-164, 195-197).
+// [mel][frame] rows, 32 consecutive frames per store.  The kernel is bound by the LDS pipe and the vector ALU together
+// (each about 70 % busy), so what shaped it is what takes work off those two: a thread keeps its residue n2 in phase 1,
+// which puts its window values and twiddles in registers for the whole kernel (a third of the LDS traffic of the phase);
+// the LDS reads of phase 3 (four items) and of a filterbank column tile are all issued before the arithmetic that uses
+// them -- the compiler cannot move a read above an earlier write to the same array on its own; tiles that lie inside
+// their utterance skip the per-frame edge selects; wave reductions are DPP register moves, not shuffles through LDS.
+// (Measured and dropped: every wave owning 8 frames end to end with no workgroup barrier at all, 12 % slower -- the
+// filterbank product then wastes half of its 16 rows and the stores come in 32-byte pieces.)
+//
+// The max-8 clamp needs the utterance-wide maximum.  Inside the transcription pipeline the rows are stored raw and the
+// consumer (conv1) clamps and scales them.  For callers that want the reference's exact output tensor the rows are stored
+// already scaled, (y + 4) / 4, and the kernel also writes the minimum of every cell of 16 frames x 16 mel rows (sixteen
+// per tile): the clamp only changes values more than eight decades under the utterance's peak (digital silence, a few
+// low filters of a clean signal), so launch_mel_clamp afterwards reads 64 bytes per tile and touches only the cells
+// whose minimum is below the floor.  x -> (x + 4) / 4 is monotonic in fp32, so clamping the scaled value to the scaled
+// floor gives the bits of scaling the clamped value.  Twiddles are rounded from double; the window multiplies the
+// samples in fp32 as the reference does (:161-164, 195-197).
 #include "mel.h"
 #include "prof.h"
 #include <algorithm>
