@@ -254,7 +254,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     // same way after the softmax.  So about one tile (8 KB) per wave is in flight at any time behind one register copy.
     // (A second register set that requests the K rows two tiles ahead was measured at 2048 clips: with three workgroups
     // per CU the 168-register budget spills and a launch takes 592 us instead of 460; with two workgroups per CU and no
-    // spill 485 us.  Twelve waves per CU with one tile each draw more than eight waves with one and a half.)
+    // spill 485 us.  Twelve waves per CU with one tile each draw more than eight waves with one and a half.  Sixteen
+    // waves -- four workgroups per CU, LDS cut to 37 KB by merging through the K tiles and keeping one zero row for the
+    // padding queries -- need 128 registers, which spills 16: 539 us.)
     // Loads use one base address per tile plus immediate offsets (no per-row clamping) and are marked non-temporal:
     // the cache is read once per step, and streaming loads that do not displace L2 lines sustain ~15 % more HBM
     // bandwidth on this GPU than plain ones (6.9 against 6.0 TB/s in a bare read loop).
