@@ -162,3 +162,19 @@ def test_mel_one_launch_clamp_path_with_silent_stretches(tiny_model, monkeypatch
     assert clamped >= 300
     for i in (0, 3, 4, 299, 599):
         _check(got[i], clips[i], 16000, m)
+
+
+def test_mel_row_stride_that_rules_out_16_byte_stores(tiny_model):
+    """An output row stride that is not a multiple of four floats: the kernel then stores frame by frame and the clamp
+    works element by element.  Same values as with the default stride, bit for bit, on a ragged batch with silent
+    stretches (clamp active), tile tails and a clip past 30 s."""
+    m = tiny_model[0]
+    lens = [160, 333, 5000, 16000, 48017, 160 * 3000 + 5, 16000 * 31 + 77, 70000]
+    audios = [synth.synth_audio(n, 300 + i) for i, n in enumerate(lens)]
+    for a in audios[2:]:
+        a[len(a) // 4: len(a) // 2] = 0.0
+    want = m.feature_extractor.process_batch(audios, 16000)
+    got = m.feature_extractor.process_batch(audios, 16000, t_stride=3001)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    _check(got[4], audios[4], 16000, m)
