@@ -254,7 +254,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void decode_attn_ke
     // same way after the softmax.  So about one tile (8 KB) per wave is in flight at any time behind one register copy.
     // (A second register set that requests the K rows two tiles ahead was measured at 2048 clips: with three workgroups
     // per CU the 168-register budget spills and a launch takes 592 us instead of 460; with two workgroups per CU and no
-    // spill 485 us.  Twelve waves per CU with one tile each draw more than eight waves with one and a half.  Sixteen
+    // spill 485 us; K and V both two tiles ahead, 207 registers, two workgroups per CU: 482 us (128 clips of the 0.6B
+    // model: 60.2 against 61.5 us).  Twelve waves per CU with one tile each draw more than eight with two.  Sixteen
     // waves -- four workgroups per CU, LDS cut to 37 KB by merging through the K tiles and keeping one zero row for the
     // padding queries -- need 128 registers, which spills 16: 539 us.)
     // Loads use one base address per tile plus immediate offsets (no per-row clamping) and are marked non-temporal:
