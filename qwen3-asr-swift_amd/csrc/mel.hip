@@ -20,7 +20,9 @@
 // them -- the compiler cannot move a read above an earlier write to the same array on its own; tiles that lie inside
 // their utterance skip the per-frame edge selects; wave reductions are DPP register moves, not shuffles through LDS.
 // (Measured and dropped: every wave owning 8 frames end to end with no workgroup barrier at all, 12 % slower -- the
-// filterbank product then wastes half of its 16 rows and the stores come in 32-byte pieces.)
+// filterbank product then wastes half of its 16 rows and the stores come in 32-byte pieces; keeping the 8-byte LDS reads
+// of phases 1 and 2 single instead of paired, which doubles their LDS rate, and a hand-written one-instruction-per-step
+// DPP reduction: no change either -- neither pipe alone is the limit.)
 //
 // The max-8 clamp needs the utterance-wide maximum.  Inside the transcription pipeline the rows are stored raw and the
 // consumer (conv1) clamps and scales them.  For callers that want the reference's exact output tensor the rows are stored
