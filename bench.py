@@ -21,6 +21,10 @@ import time
 
 import numpy as np
 
+# Multi-process GPU work on this platform needs dmabuf IPC (RCCL's peer mappings fail with "hipIpcGetMemHandle: invalid
+# argument" under the legacy mode); set before anything initialises HIP, and only if the caller has not decided.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "qwen3-asr-swift_amd"))
