@@ -22,7 +22,8 @@ constexpr int TOK_ASSISTANT = 77091;
 constexpr int ENC_CHUNK_BUDGET = 5120;  // most chunks per encoder pass (170 clips of 30 s; conv1's output is 3 MB per chunk;
                                         // measured: 960 -> 673 ms, 3840 -> 590 ms, 7680 -> 581 ms per 1024 clips)
 constexpr int POLL_STEPS = 8;
-constexpr int SPLIT_MIN_ROWS = 1024;    // groups from this size on decode as two halves on disjoint sets of compute units
+constexpr int SPLIT_MIN_ROWS = 640;     // groups from this size on decode as two halves on disjoint sets of compute units
+constexpr int SPLIT_MIN_ROWS_HEAVY_Q4 = 1024;   // ... for 4-bit weights at the 1.7B widths (not measured below 1024)
 constexpr int SPLIT_MERGE_ROWS = 512;   // ... until this few utterances are still running
 
 inline int conv_len(int n) { return (n - 1) / 2 + 1; }
@@ -525,12 +526,15 @@ q3asr_model::DecodePlan decode_plan(Ctx& c, int rows, GemmWFmt wf, int cus, hipS
 // every kernel).  Q3ASR_DECODE_ATT_CUS pins the share (tests, tuning).  Measured at 2048 clips against one stream:
 // 1.7B bf16 -9 % decode time with 160 of 256 CUs (128: -3 %, 144: slower, the 256-wide projection tiles fill 96 CUs in
 // whole rounds), 0.6B bf16 -2.5 %, 0.6B 4-bit -4.6 %; the 1.7B 4-bit projections (dequantisation-bound) are too slow
-// on 96 CUs (+19 %) and take half of the device (-4 %).  Groups below 1024 utterances are faster on one stream.
+// on 96 CUs (+19 %) and take half of the device (-4 %).  By group size, decode time of the split against one stream:
+// 1.7B bf16 256 clips +39 %, 384 +11 %, 512 +13 %, 640 -11 %, 768 -14 %, 896 -11 % (two halves of 256 rows are one row
+// tile each for the 256-wide projection kernel, which then leaves most of its 96 CUs idle); 0.6B bf16 256 +13 %,
+// 512 -2 %; 0.6B 4-bit 256 +10 %, 512 -9 %.
 int decode_att_cus(const q3asr_model* m, int b) {
     const int cus_all = device_cus();
     const char* env_att = getenv("Q3ASR_DECODE_ATT_CUS");
     const bool heavy_q4 = m->cfg.weight_format == 1 && m->cfg.hidden >= 2048;
-    int att_cus = (env_att ? atoi(env_att) : (b >= SPLIT_MIN_ROWS ? (heavy_q4 ? cus_all / 2 : cus_all * 5 / 8) : 0)) & ~7;
+    int att_cus = (env_att ? atoi(env_att) : (b >= (heavy_q4 ? SPLIT_MIN_ROWS_HEAVY_Q4 : SPLIT_MIN_ROWS) ? (heavy_q4 ? cus_all / 2 : cus_all * 5 / 8) : 0)) & ~7;
     if (b < 2 || cus_all % 8 != 0 || att_cus < 8 || cus_all - att_cus < 8) att_cus = 0;
     return att_cus;
 }

@@ -158,7 +158,7 @@ def test_split_decode_equals_one_stream(pinned_model, monkeypatch):
     audios = [synth.synth_audio(n, 80 + i) for i, n in enumerate((20000, 100000, 16000, 64000, 33333))]
     # the library's own choice: one stream for small groups, 5/8 of the compute units for the attention of large ones
     monkeypatch.delenv("Q3ASR_DECODE_ATT_CUS", raising=False)
-    assert m.decode_attention_cus(5) == 0 and m.decode_attention_cus(1023) == 0
+    assert m.decode_attention_cus(5) == 0 and m.decode_attention_cus(639) == 0 and m.decode_attention_cus(640) > 0
     big = m.decode_attention_cus(2048)
     assert big > 0 and big % 8 == 0
     monkeypatch.setenv("Q3ASR_DECODE_ATT_CUS", "64")
